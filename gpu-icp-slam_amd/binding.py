@@ -1,0 +1,304 @@
+"""ctypes binding of include/pfslam.h (libpfslam_hip.so).  No fallback of any kind."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NODE_DTYPE = np.dtype(
+    [("axis", "<i4"), ("left", "<i4"), ("right", "<i4"), ("parent", "<i4"),
+     ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4")])
+PARTICLE_DTYPE = np.dtype(
+    {"names": ["x", "y", "theta", "w", "cluster", "map"],
+     "formats": ["<f4", "<f4", "<f4", "<f4", "u1", "<u8"],
+     "offsets": [0, 4, 8, 12, 16, 24], "itemsize": 32})
+
+# every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
+    "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
+    "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
+    "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
+    "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
+    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("n_particles", C.c_int32), ("n_beams", C.c_int32),
+                ("map_scale_x", C.c_float), ("map_scale_y", C.c_float),
+                ("map_res_x", C.c_float), ("map_res_y", C.c_float),
+                ("kd_capacity", C.c_int32), ("device", C.c_int32),
+                ("strict_host_mirror", C.c_int32), ("free_upload_bug", C.c_int32),
+                ("balance_period", C.c_int32), ("global_offset", C.c_int32), ("global_n", C.c_int32),
+                ("reserved_", C.c_int32 * 3)]
+
+
+class PfSlamError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Build (if stale) and load libpfslam_hip.so.  Raises if that is not possible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.stale():
+        try:
+            _build.build()
+        except Exception as e:  # a prebuilt .so that travelled with the snapshot is still usable
+            if not os.path.exists(path):
+                raise PfSlamError("libpfslam_hip.so is missing and could not be built: %s" % e)
+    L = C.CDLL(path)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    L.pfslam_last_error.restype = C.c_char_p
+    L.pfslam_default_config.restype = None
+    L.pfslam_default_config.argtypes = [vp]
+    L.pfslam_create.argtypes = [vp, vp]
+    L.pfslam_destroy.argtypes = [vp]
+    L.pfslam_set_stream.argtypes = [vp, vp]
+    L.pfslam_synchronize.argtypes = [vp]
+    L.pfslam_step.argtypes = [vp, i32, vp]
+    L.pfslam_get_pose.argtypes = [vp, vp]
+    L.pfslam_get_particles.argtypes = [vp, vp, vp]
+    L.pfslam_get_map.argtypes = [vp, vp, vp]
+    L.pfslam_get_grid.argtypes = [vp, vp, vp, vp]
+    L.pfslam_get_trace.argtypes = [vp, vp]
+    L.pfslam_get_cells.argtypes = [vp, i32, vp, i32, vp]
+    L.pfslam_set_map.argtypes = [vp, vp, i32]
+    L.pfslam_set_particles.argtypes = [vp, vp, i32]
+    L.pfslam_set_scan.argtypes = [vp, vp, i32]
+    L.pfslam_set_pose.argtypes = [vp, vp]
+    L.pfslam_set_grid.argtypes = [vp, vp, i32, i32]
+    L.pfslam_motion_update.argtypes = [vp, i32]
+    L.pfslam_score_kd.argtypes = [vp, vp]
+    L.pfslam_measurement_update.argtypes = [vp, vp, vp, vp]
+    L.pfslam_icp.argtypes = [vp, vp, vp, vp]
+    L.pfslam_update_map_kd.argtypes = [vp]
+    L.pfslam_resample.argtypes = [vp, i32, vp, vp]
+    L.pfslam_score_grid.argtypes = [vp, vp]
+    L.pfslam_update_map_grid.argtypes = [vp]
+    L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
+    L.pfslam_measurement_local.argtypes = [vp]
+    L.pfslam_measurement_apply.argtypes = [vp, vp, vp, vp]
+    L.pfslam_device_ptr.argtypes = [vp, i32, vp, vp]
+    L.pfslam_time_score_kd.argtypes = [vp, i32, vp]
+    L.pfslam_set_variant.argtypes = [vp, i32]
+    L.pfslam_kd_create.argtypes = [vp, i32, vp]
+    L.pfslam_kd_insert_node.argtypes = [vp, vp, i32]
+    L.pfslam_kd_balance.argtypes = [vp, i32]
+    L.pfslam_debug_math.argtypes = [vp, i32, vp, i32, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what=""):
+    if rc != 0:
+        raise PfSlamError("%s failed: %s" % (what, load().pfslam_last_error().decode()))
+
+
+def device_count():
+    return load().pfslam_device_count()
+
+
+# ---- host-side map structure (no GPU needed) -------------------------------------------------
+def kd_create(points_xyzw):
+    pts = np.ascontiguousarray(points_xyzw, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros(len(pts), dtype=NODE_DTYPE)
+    _chk(load().pfslam_kd_create(_p(pts), len(pts), _p(out)), "pfslam_kd_create")
+    return out
+
+
+def kd_insert_node(nodes, size, p4):
+    p = np.ascontiguousarray(p4, dtype=np.float32)
+    _chk(load().pfslam_kd_insert_node(_p(p), _p(nodes), size), "pfslam_kd_insert_node")
+
+
+def kd_balance(nodes, size):
+    _chk(load().pfslam_kd_balance(_p(nodes), size), "pfslam_kd_balance")
+
+
+class PfSlam:
+    """One handle = one GPU's shard of particles + a replica of the map."""
+
+    def __init__(self, n_particles, n_beams=1081, kd_capacity=1 << 20, device=0, strict_host_mirror=1,
+                 free_upload_bug=0, balance_period=100, global_offset=0, global_n=0):
+        L = load()
+        cfg = Config()
+        L.pfslam_default_config(C.byref(cfg))
+        cfg.n_particles, cfg.n_beams, cfg.kd_capacity, cfg.device = n_particles, n_beams, kd_capacity, device
+        cfg.strict_host_mirror, cfg.free_upload_bug, cfg.balance_period = strict_host_mirror, free_upload_bug, balance_period
+        cfg.global_offset, cfg.global_n = global_offset, global_n
+        self.cfg = cfg
+        self.n, self.nb = n_particles, n_beams
+        self._h = C.c_void_p()
+        _chk(L.pfslam_create(C.byref(cfg), C.byref(self._h)), "pfslam_create")
+        self.L = L
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.L.pfslam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- uploads
+    def set_map(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        _chk(self.L.pfslam_set_map(self._h, _p(nodes), len(nodes)), "pfslam_set_map")
+
+    def set_particles(self, particles):
+        particles = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+        _chk(self.L.pfslam_set_particles(self._h, _p(particles), len(particles)), "pfslam_set_particles")
+
+    def set_scan(self, scan):
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        _chk(self.L.pfslam_set_scan(self._h, _p(scan), len(scan)), "pfslam_set_scan")
+
+    def set_pose(self, pose):
+        pose = np.ascontiguousarray(pose, dtype=np.float32)
+        _chk(self.L.pfslam_set_pose(self._h, _p(pose)), "pfslam_set_pose")
+
+    def set_grid(self, grid):
+        grid = np.ascontiguousarray(grid, dtype=np.int8)
+        _chk(self.L.pfslam_set_grid(self._h, _p(grid), grid.shape[0], grid.shape[1]), "pfslam_set_grid")
+
+    def set_stream(self, stream_ptr):
+        _chk(self.L.pfslam_set_stream(self._h, C.c_void_p(stream_ptr)), "pfslam_set_stream")
+
+    def set_variant(self, v):
+        _chk(self.L.pfslam_set_variant(self._h, v), "pfslam_set_variant")
+
+    def synchronize(self):
+        _chk(self.L.pfslam_synchronize(self._h), "pfslam_synchronize")
+
+    # -- stages
+    def motion_update(self, frame):
+        _chk(self.L.pfslam_motion_update(self._h, frame), "pfslam_motion_update")
+
+    def score_kd(self, fetch=True):
+        if not fetch:
+            _chk(self.L.pfslam_score_kd(self._h, None), "pfslam_score_kd")
+            return None
+        fit = np.empty(self.n, np.float32)
+        _chk(self.L.pfslam_score_kd(self._h, _p(fit)), "pfslam_score_kd")
+        return fit
+
+    def time_score_kd(self, iters):
+        ms = C.c_float()
+        _chk(self.L.pfslam_time_score_kd(self._h, iters, C.byref(ms)), "pfslam_time_score_kd")
+        return ms.value
+
+    def measurement_update(self):
+        best, fmin, fmax = C.c_int(), C.c_float(), C.c_float()
+        _chk(self.L.pfslam_measurement_update(self._h, C.byref(best), C.byref(fmin), C.byref(fmax)),
+             "pfslam_measurement_update")
+        return best.value, fmin.value, fmax.value
+
+    def measurement_local(self):
+        _chk(self.L.pfslam_measurement_local(self._h), "pfslam_measurement_local")
+
+    def measurement_apply(self):
+        best, fmin, fmax = C.c_int(), C.c_float(), C.c_float()
+        _chk(self.L.pfslam_measurement_apply(self._h, C.byref(best), C.byref(fmin), C.byref(fmax)),
+             "pfslam_measurement_apply")
+        return best.value, fmin.value, fmax.value
+
+    def icp(self, start):
+        start = np.ascontiguousarray(start, dtype=np.float32)
+        out = np.zeros(3, np.float32)
+        dbg = np.zeros(32, np.float32)
+        _chk(self.L.pfslam_icp(self._h, _p(start), _p(out), _p(dbg)), "pfslam_icp")
+        return out, dbg
+
+    def update_map_kd(self):
+        _chk(self.L.pfslam_update_map_kd(self._h), "pfslam_update_map_kd")
+
+    def resample(self, frame):
+        did, neff = C.c_int(), C.c_float()
+        _chk(self.L.pfslam_resample(self._h, frame, C.byref(did), C.byref(neff)), "pfslam_resample")
+        return did.value, neff.value
+
+    def score_grid(self):
+        fit = np.empty(self.n, np.int32)
+        _chk(self.L.pfslam_score_grid(self._h, _p(fit)), "pfslam_score_grid")
+        return fit
+
+    def update_map_grid(self):
+        _chk(self.L.pfslam_update_map_grid(self._h), "pfslam_update_map_grid")
+
+    def step(self, frame, scan):
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        _chk(self.L.pfslam_step(self._h, frame, _p(scan)), "pfslam_step")
+
+    def traverse(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        best = np.empty(len(xyz), np.int32)
+        _chk(self.L.pfslam_traverse(self._h, _p(xyz), len(xyz), _p(best)), "pfslam_traverse")
+        return best
+
+    def debug_math(self, which, x):
+        x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        out = np.empty(len(x) * (2 if which == 0 else 1), np.float32)
+        _chk(self.L.pfslam_debug_math(self._h, which, _p(x), len(x), _p(out)), "pfslam_debug_math")
+        return out.reshape(-1, 2) if which == 0 else out
+
+    # -- read-back
+    @property
+    def pose(self):
+        out = np.zeros(3, np.float32)
+        _chk(self.L.pfslam_get_pose(self._h, _p(out)), "pfslam_get_pose")
+        return out
+
+    def particles(self):
+        ptr, n = C.c_void_p(), C.c_int()
+        _chk(self.L.pfslam_get_particles(self._h, C.byref(ptr), C.byref(n)), "pfslam_get_particles")
+        buf = (C.c_char * (32 * n.value)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=PARTICLE_DTYPE).copy()
+
+    def map(self):
+        ptr, n = C.c_void_p(), C.c_int()
+        _chk(self.L.pfslam_get_map(self._h, C.byref(ptr), C.byref(n)), "pfslam_get_map")
+        if n.value == 0:
+            return np.zeros(0, NODE_DTYPE)
+        buf = (C.c_char * (32 * n.value)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=NODE_DTYPE).copy()
+
+    def grid(self):
+        ptr, dx, dy = C.c_void_p(), C.c_int(), C.c_int()
+        _chk(self.L.pfslam_get_grid(self._h, C.byref(ptr), C.byref(dx), C.byref(dy)), "pfslam_get_grid")
+        buf = (C.c_char * (dx.value * dy.value)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.int8).reshape(dx.value, dy.value).copy()
+
+    def trace(self):
+        t = np.zeros(8, np.int32)
+        _chk(self.L.pfslam_get_trace(self._h, _p(t)), "pfslam_get_trace")
+        return {"best": int(t[0]), "resampled": int(t[1]), "n_wall": int(t[2]), "n_free": int(t[3]),
+                "n_insert": int(t[4]), "neff": float(t[5:6].view(np.float32)[0]), "kd_size": int(t[6])}
+
+    def cells(self, which):
+        cap = 1600 * 1600
+        out = np.empty(cap, np.int32)
+        n = C.c_int()
+        _chk(self.L.pfslam_get_cells(self._h, which, _p(out), cap, C.byref(n)), "pfslam_get_cells")
+        return out[:n.value].copy()
+
+    def device_ptr(self, which):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _chk(self.L.pfslam_device_ptr(self._h, which, C.byref(ptr), C.byref(nbytes)), "pfslam_device_ptr")
+        return ptr.value, nbytes.value

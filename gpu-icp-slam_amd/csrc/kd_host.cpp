@@ -1,0 +1,79 @@
+// kd_host.cpp -- host-side map structure: the counterpart of the reference's
+// KDTree::Create / InsertList / InsertNode / Balance (src/kdtree.cpp:25-105).
+//
+// The tree is the pre-order array the kernels traverse: node i's left child is i+1, its right
+// child i+mid+1, -1 = none; axis cycles x,y,z from the root.  The topology the reference
+// produces is whatever libstdc++'s (unstable) std::sort does with the tied keys of grid-snapped
+// points, so the build sorts the same sequences with the same comparison -- but on sub-ranges of
+// one scratch buffer rather than on a fresh std::vector copy per recursion level.
+#include "../../include/pfslam.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+struct Pt { float x, y, z, w; };
+inline bool byX(const Pt &a, const Pt &b) { return a.x < b.x; }
+inline bool byY(const Pt &a, const Pt &b) { return a.y < b.y; }
+inline bool byZ(const Pt &a, const Pt &b) { return a.z < b.z; }
+
+void build_range(std::vector<Pt> &buf, int lo, int hi, pfslam_node *out, int idx, int parent)
+{
+    const int axis = parent < 0 ? 0 : (out[parent].axis + 1) % 3;
+    auto first = buf.begin() + lo, last = buf.begin() + hi;
+    switch (axis) {
+    case 0: std::sort(first, last, byX); break;
+    case 1: std::sort(first, last, byY); break;
+    default: std::sort(first, last, byZ); break;
+    }
+    const int count = hi - lo, mid = count / 2;
+    const Pt &m = buf[lo + mid];
+    out[idx] = pfslam_node{axis, -1, -1, parent, m.x, m.y, m.z, m.w};
+    if (mid > 0) {
+        out[idx].left = idx + 1;
+        build_range(buf, lo, lo + mid, out, idx + 1, idx);
+    }
+    if (mid < count - 1) {
+        out[idx].right = idx + mid + 1;
+        build_range(buf, lo + mid + 1, hi, out, idx + mid + 1, idx);
+    }
+}
+} // namespace
+
+extern "C" int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out)
+{
+    if (n < 0 || (n > 0 && (!pts_xyzw || !out))) return 1;
+    if (n == 0) return 0;
+    std::vector<Pt> buf(n);
+    for (int i = 0; i < n; i++) buf[i] = Pt{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
+    std::sort(buf.begin(), buf.end(), byX); // KDTree::Create pre-sorts on x before the recursive sort
+    build_range(buf, 0, n, out, 0, -1);
+    return 0;
+}
+
+extern "C" int pfslam_kd_insert_node(const float p[4], pfslam_node *list, int list_size)
+{
+    if (!p || !list || list_size <= 0) return 1;
+    int cur = 0, at = 0, axis = 0;
+    bool goLeft = false;
+    while (cur != -1) {
+        at = cur;
+        axis = list[at].parent == -1 ? 0 : (list[list[at].parent].axis + 1) % 3;
+        const float key = axis == 0 ? list[at].x : axis == 1 ? list[at].y : list[at].z;
+        goLeft = p[axis] < key;
+        cur = goLeft ? list[at].left : list[at].right;
+    }
+    (goLeft ? list[at].left : list[at].right) = list_size;
+    list[list_size] = pfslam_node{(axis + 1) % 3, -1, -1, at, p[0], p[1], p[2], p[3]};
+    return 0;
+}
+
+extern "C" int pfslam_kd_balance(pfslam_node *list, int n)
+{
+    if (n < 0 || (n > 0 && !list)) return 1;
+    std::vector<float> pts(4 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        pts[4 * i] = list[i].x; pts[4 * i + 1] = list[i].y; pts[4 * i + 2] = list[i].z; pts[4 * i + 3] = list[i].w;
+    }
+    return pfslam_kd_create(pts.data(), n, list);
+}

@@ -1,0 +1,642 @@
+// pfslam_hip.hip -- libpfslam_hip.so: gfx950 kernels + the C-ABI of include/pfslam.h.
+//
+// MI355X-native implementation of the particle-filter SLAM inner loop the reference implements
+// in src/kernel.cu.  Written for CDNA4 only (wave64, 256 CUs / 8 XCDs, 160 KB LDS per CU):
+// no CUDA compatibility layer, no CPU fallback -- every entry point that needs the GPU fails
+// loudly without one.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+#include "../../include/pfslam.h"
+#include "kd_device.h"
+#include "pf_math.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// constants of the reference (kernel.cu:30-52)
+// ------------------------------------------------------------------------------------------
+#define PF_LIDAR_RANGE 20.0f
+#define PF_FREE_WEIGHT (-1)
+#define PF_OCCUPIED_WEIGHT 4
+#define PF_EFFECTIVE_PARTICLES .7
+#define PF_CLAMP_VAL 113.0f /* (1 << 7) - 15, kernel.cu:518,1355 */
+#define PF_SVD_EPSILON 0.00001f
+#define PF_SUM_TILE 4096
+#define PF_SCAN_TILE 1024
+#define PF_SCAN_CHUNK 16
+
+static thread_local std::string g_err;
+static int fail(const std::string &m)
+{
+    g_err = m;
+    return 1;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" +   \
+                        std::to_string(__LINE__) + ")");                                               \
+    } while (0)
+#define CHK(expr)                                                                                      \
+    do {                                                                                               \
+        int r__ = (expr);                                                                              \
+        if (r__) return r__;                                                                           \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct HostHeader { // written by the device each step, read back in one D2H
+    int32_t n_wall, n_free, n_new, pad0;
+    float neff, r, r2, pad1;
+    float pose[4];
+    float start[4];
+    int64_t stats[8];
+};
+
+struct pfslam_handle {
+    pfslam_config cfg;
+    int n = 0, nb = 0, dimx = 0, dimy = 0;
+    int gn = 0, goff = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int variant = 0;
+    // particles, SoA; pos double-buffered for the resample gather
+    float *x = nullptr, *y = nullptr, *th = nullptr, *w = nullptr, *wm = nullptr;
+    float *x2 = nullptr, *y2 = nullptr, *th2 = nullptr;
+    float *scan = nullptr;
+    // map
+    int kd_size = 0, kd_cap = 0, planar = 1;
+    uint4 *hot = nullptr;
+    int *parent = nullptr;
+    float *kz = nullptr, *kw = nullptr;
+    std::vector<pfslam_node> h_nodes; // host mirror (topology + positions; w refreshed on demand)
+    // scoring
+    float *fit = nullptr, *partial = nullptr;
+    size_t partial_elems = 0;
+    int64_t *stats = nullptr;
+    float *pose = nullptr;  // device robotPos[4]
+    float *start = nullptr; // device best-particle pose [4]
+    float h_pose[3] = {0, 0, 0};
+    // ICP scratch
+    float *icp_tar = nullptr, *icp_cor = nullptr, *icp_dbg = nullptr;
+    // map update scratch
+    uint8_t *free_mask = nullptr, *wall_mask = nullptr;
+    int *blk_cnt = nullptr; // per block wall/free counts then offsets
+    int *wall_cell = nullptr, *free_cell = nullptr;
+    float4 *wall_pts = nullptr, *free_pts = nullptr;
+    int *wall_c = nullptr, *free_c = nullptr;
+    float4 *new_pts = nullptr;
+    int *counts = nullptr; // [0] n_wall [1] n_free [2] n_new
+    int max_free = 0, max_wall = 0;
+    // resample scratch
+    float *tile_r = nullptr, *tile_r2 = nullptr, *sums = nullptr; // sums: [r, r2, neff]
+    float *cdf = nullptr, *chunk_max = nullptr, *tile_tot = nullptr, *tile_off = nullptr, *tile_pmax = nullptr;
+    int *src = nullptr;
+    // grid path
+    int8_t *grid = nullptr;
+    int32_t *fit_i = nullptr;
+    std::vector<int8_t> h_grid;
+    // host mirrors / read-back
+    HostHeader *h_hdr = nullptr; // pinned
+    HostHeader *d_hdr = nullptr;
+    std::vector<pfslam_particle> h_particles;
+    std::vector<float> h_tmp;
+    std::vector<float4> h_new;
+    int32_t trace[8] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// ==========================================================================================
+// kernels
+// ==========================================================================================
+
+// ---- A3: dispersion (ParticleAddNoise / kernAddNoise, kernel.cu:375-397) ------------------
+// One thread per particle, coalesced SoA.  `wm` is the reference's host-side particle array:
+// PFMotionUpdate starts with an H2D of it (kernel.cu:408), which -- because the measurement
+// update only reads back the first half of the array (kernel.cu:1341, H11) -- resets the
+// weights of the second half to their pre-measurement values.
+__global__ __launch_bounds__(256) void k_motion(float *__restrict__ x, float *__restrict__ y,
+                                                float *__restrict__ th, float *__restrict__ w,
+                                                const float *__restrict__ wm, int n, int frame, int goff)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    w[i] = wm[i];
+    uint32_t e2 = pf::engine_seed(frame, goff + i, 0);
+    const float sx = 0.015, sy = 0.015, st = .01; // COV, kernel.cu:45 (used as std-dev, H10)
+    float nx = pf::normal(e2, 0.0f, sx);
+    float ny = pf::normal(e2, 0.0f, sy);
+    float nt = pf::normal(e2, 0.0f, st);
+    x[i] += nx;
+    y[i] += ny;
+    th[i] += nt;
+}
+
+// ---- A5: scan-match score (EvaluateParticleKD / kernEvaluateParticlesKD, kernel.cu:1198-1308)
+// Lane = particle, the wave walks a chunk of beams: all 64 lanes query the same beam from
+// near-identical poses, so their descents touch the same nodes until the last levels (one
+// cache line per step instead of 64) and the per-lane sum keeps the reference's beam order.
+// blockIdx.y selects the beam chunk; partial sums are combined by k_reduce_partials.
+template <bool PLANAR>
+__global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, const float *__restrict__ py,
+                                                  const float *__restrict__ pth, int n,
+                                                  const float *__restrict__ scan, int nb, int beams_per_chunk,
+                                                  pf::KdView tree, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * beams_per_chunk;
+    const int j1 = min(nb, j0 + beams_per_chunk);
+    if (i >= n) return;
+    const float x = px[i], y = py[i], th = pth[i];
+    float acc = 0.0f;
+    for (int j = j0; j < j1; j++) {
+        float wx, wy;
+        pf::clean_lidar_scan(j, scan[j], th, wx, wy);
+        if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
+            wx += x;
+            wy += y;
+            const int b = pf::kd_nearest_ref<PLANAR>(tree, wx, wy, 0.0f);
+            acc += tree.w[b];
+        }
+    }
+    out[(size_t)blockIdx.y * n + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ partial, int n, int chunks,
+                                                         float *__restrict__ fit)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = partial[i];
+    for (int c = 1; c < chunks; c++) a += partial[(size_t)c * n + i];
+    fit[i] = a;
+}
+
+// ---- findCorrespondenceIndexKD (kernel.cu:924-972) over an arbitrary xyz batch --------------
+template <bool PLANAR>
+__global__ __launch_bounds__(256) void k_traverse(const float *__restrict__ xyz, int n, pf::KdView tree,
+                                                  int *__restrict__ best)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    best[i] = pf::kd_nearest_ref<PLANAR>(tree, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+}
+
+// ---- debug: evaluate the pf_math specification on the device (parity tests) -----------------
+__global__ void k_debug_math(int which, const float *__restrict__ in, int n, float *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) {
+        float s, c;
+        pf::sincosf_spec(in[i], s, c);
+        out[2 * i] = s;
+        out[2 * i + 1] = c;
+    } else if (which == 1) {
+        out[i] = pf::erfcinvf_spec(in[i]);
+    } else if (which == 2) {
+        out[i] = pf::asinf_spec(in[i]);
+    } else if (which == 3) {
+        out[i] = pf::rsqrtf_spec(in[i]);
+    } else if (which == 4) {
+        out[i] = pf::fsqrt(in[i]);
+    } else if (which == 5) {
+        out[i] = pf::fdiv(in[i], 0.025f);
+    }
+}
+
+#include "pfslam_stages.hip.inc"
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" const char *pfslam_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pfslam_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -(int)e;
+    return n;
+}
+
+extern "C" void pfslam_default_config(pfslam_config *cfg)
+{
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->n_particles = 1000; // PARTICLE_COUNT, kernel.cu:30
+    cfg->n_beams = 1081;
+    cfg->map_scale_x = cfg->map_scale_y = 40.0f;
+    cfg->map_res_x = cfg->map_res_y = 0.025f;
+    cfg->kd_capacity = 1 << 20;
+    cfg->device = 0;
+    cfg->strict_host_mirror = 1;
+    cfg->free_upload_bug = 0;
+    cfg->balance_period = 100;
+}
+
+template <typename T>
+static int dalloc(T **p, size_t count)
+{
+    HIPCHK(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return 0;
+}
+
+static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw}; }
+
+extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
+{
+    if (!cfg || !out) return fail("pfslam_create: null argument");
+    if (cfg->n_particles <= 0 || cfg->n_beams <= 0 || cfg->kd_capacity <= 0)
+        return fail("pfslam_create: n_particles, n_beams and kd_capacity must be positive");
+    if (cfg->n_particles > (1 << 24)) return fail("pfslam_create: at most 2^24 particles per handle");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(std::string("pfslam_create: no HIP device available (") + hipGetErrorString(e) +
+                    "); this library has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("pfslam_create: bad device ordinal");
+    HIPCHK(hipSetDevice(cfg->device));
+    pfslam_handle *h = new pfslam_handle();
+    h->cfg = *cfg;
+    h->n = cfg->n_particles;
+    h->nb = cfg->n_beams;
+    h->gn = cfg->global_n > 0 ? cfg->global_n : cfg->n_particles;
+    h->goff = cfg->global_offset;
+    h->dimx = (int)(cfg->map_scale_x / cfg->map_res_x); // map_dim, kernel.cu:120
+    h->dimy = (int)(cfg->map_scale_y / cfg->map_res_y);
+    h->kd_cap = cfg->kd_capacity;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    const size_t n = h->n, M = (size_t)h->dimx * h->dimy;
+    CHK(dalloc(&h->x, n)); CHK(dalloc(&h->y, n)); CHK(dalloc(&h->th, n)); CHK(dalloc(&h->w, n)); CHK(dalloc(&h->wm, n));
+    CHK(dalloc(&h->x2, n)); CHK(dalloc(&h->y2, n)); CHK(dalloc(&h->th2, n));
+    CHK(dalloc(&h->scan, (size_t)h->nb));
+    CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
+    CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
+    CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
+    CHK(dalloc(&h->stats, 8)); CHK(dalloc(&h->pose, 4)); CHK(dalloc(&h->start, 4));
+    CHK(dalloc(&h->icp_tar, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_cor, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_dbg, 32));
+    CHK(dalloc(&h->free_mask, M)); CHK(dalloc(&h->wall_mask, M));
+    h->max_wall = h->nb;
+    h->max_free = (int)std::min<size_t>(M, (size_t)h->nb * (size_t)std::max(h->dimx, h->dimy));
+    CHK(dalloc(&h->blk_cnt, 2 * ((M + 4095) / 4096) + 8));
+    CHK(dalloc(&h->wall_cell, (size_t)h->max_wall)); CHK(dalloc(&h->free_cell, (size_t)h->max_free));
+    CHK(dalloc(&h->wall_pts, (size_t)h->max_wall)); CHK(dalloc(&h->free_pts, (size_t)h->max_free));
+    CHK(dalloc(&h->wall_c, (size_t)h->max_wall)); CHK(dalloc(&h->free_c, (size_t)h->max_free));
+    CHK(dalloc(&h->new_pts, (size_t)h->max_wall)); CHK(dalloc(&h->counts, 8));
+    const size_t nt_sum = (n + PF_SUM_TILE - 1) / PF_SUM_TILE, nt_scan = (n + PF_SCAN_TILE - 1) / PF_SCAN_TILE;
+    CHK(dalloc(&h->tile_r, nt_sum)); CHK(dalloc(&h->tile_r2, nt_sum)); CHK(dalloc(&h->sums, 4));
+    CHK(dalloc(&h->cdf, n)); CHK(dalloc(&h->chunk_max, (n + PF_SCAN_CHUNK - 1) / PF_SCAN_CHUNK));
+    CHK(dalloc(&h->tile_tot, nt_scan)); CHK(dalloc(&h->tile_off, nt_scan)); CHK(dalloc(&h->tile_pmax, nt_scan));
+    CHK(dalloc(&h->src, n));
+    CHK(dalloc(&h->grid, M));
+    CHK(dalloc(&h->d_hdr, 1));
+    HIPCHK(hipHostMalloc((void **)&h->h_hdr, sizeof(HostHeader)));
+    memset(h->h_hdr, 0, sizeof(HostHeader));
+    h->h_nodes.reserve(1024);
+    // particleFilterInit (kernel.cu:122-132): grid = -100, particles at the origin with w = 1, robotPos = 0
+    std::vector<float> ones(n, 1.0f);
+    HIPCHK(hipMemsetAsync(h->x, 0, n * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->y, 0, n * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->th, 0, n * 4, h->stream));
+    HIPCHK(hipMemcpyAsync(h->w, ones.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->wm, ones.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->pose, 0, 16, h->stream));
+    HIPCHK(hipMemsetAsync(h->start, 0, 16, h->stream));
+    HIPCHK(hipMemsetAsync(h->grid, 0x9c /* -100 */, M, h->stream));
+    HIPCHK(hipMemsetAsync(h->stats, 0, 64, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = h;
+    return 0;
+}
+
+extern "C" int pfslam_destroy(pfslam_handle *h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw,
+                    h->fit, h->fit_i, h->partial, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
+                    h->free_mask, h->wall_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
+                    h->wall_c, h->free_c, h->new_pts, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
+                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_hdr};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->h_hdr) (void)hipHostFree(h->h_hdr);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int pfslam_set_stream(pfslam_handle *h, void *hip_stream)
+{
+    if (!h) return fail("null handle");
+    if (h->own_stream && h->stream) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamDestroy(h->stream));
+    }
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return 0;
+}
+
+extern "C" int pfslam_synchronize(pfslam_handle *h)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pfslam_set_variant(pfslam_handle *h, int variant)
+{
+    if (!h) return fail("null handle");
+    h->variant = variant;
+    return 0;
+}
+
+// upload a tree: host mirror + split device layout
+static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
+{
+    if (n > h->kd_cap) return fail("map larger than kd_capacity");
+    h->h_nodes.assign(nodes, nodes + n);
+    h->kd_size = n;
+    if (n == 0) return 0;
+    std::vector<uint4> hot(n);
+    std::vector<int> par(n);
+    std::vector<float> z(n), w(n);
+    int planar = 1;
+    for (int i = 0; i < n; i++) {
+        const pfslam_node &nd = nodes[i];
+        if (nd.axis < 0 || nd.axis > 2 || nd.left < -1 || nd.left >= n || nd.right < -1 || nd.right >= n ||
+            nd.parent < -1 || nd.parent >= n)
+            return fail("pfslam_set_map: node " + std::to_string(i) + " has out-of-range links or axis");
+        hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right);
+        par[i] = nd.parent;
+        z[i] = nd.z;
+        w[i] = nd.w;
+        if (nd.z != 0.0f) planar = 0;
+    }
+    h->planar = planar;
+    HIPCHK(hipMemcpyAsync(h->hot, hot.data(), (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->kw, w.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pfslam_set_map(pfslam_handle *h, const pfslam_node *nodes, int n)
+{
+    if (!h || (n > 0 && !nodes) || n < 0) return fail("pfslam_set_map: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return upload_tree(h, nodes, n);
+}
+
+extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, int n)
+{
+    if (!h || !p || n != h->n) return fail("pfslam_set_particles: n must equal cfg.n_particles");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::vector<float> tmp(4 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        tmp[i] = p[i].x; tmp[n + i] = p[i].y; tmp[2 * (size_t)n + i] = p[i].theta; tmp[3 * (size_t)n + i] = p[i].w;
+    }
+    HIPCHK(hipMemcpyAsync(h->x, &tmp[0], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->y, &tmp[n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->th, &tmp[2 * (size_t)n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->w, &tmp[3 * (size_t)n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->wm, &tmp[3 * (size_t)n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_beams)
+{
+    if (!h || !scan_host || n_beams != h->nb) return fail("pfslam_set_scan: n_beams must equal cfg.n_beams");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(h->scan, scan_host, (size_t)n_beams * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream)); // scan_host is pageable: do not return before it is consumed
+    return 0;
+}
+
+extern "C" int pfslam_set_pose(pfslam_handle *h, const float pose[3])
+{
+    if (!h || !pose) return fail("pfslam_set_pose: bad argument");
+    float p4[4] = {pose[0], pose[1], pose[2], 0.0f};
+    memcpy(h->h_pose, pose, 12);
+    HIPCHK(hipMemcpyAsync(h->pose, p4, 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pfslam_get_particles(pfslam_handle *h, const pfslam_particle **out, int *n)
+{
+    if (!h || !out || !n) return fail("pfslam_get_particles: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t N = h->n;
+    h->h_tmp.resize(4 * N);
+    HIPCHK(hipMemcpyAsync(&h->h_tmp[0], h->x, N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&h->h_tmp[N], h->y, N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&h->h_tmp[2 * N], h->th, N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&h->h_tmp[3 * N], h->w, N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->h_particles.resize(N);
+    for (size_t i = 0; i < N; i++) {
+        pfslam_particle &p = h->h_particles[i];
+        memset(&p, 0, sizeof(p));
+        p.x = h->h_tmp[i]; p.y = h->h_tmp[N + i]; p.theta = h->h_tmp[2 * N + i]; p.w = h->h_tmp[3 * N + i];
+    }
+    *out = h->h_particles.data();
+    *n = (int)N;
+    return 0;
+}
+
+extern "C" int pfslam_get_map(pfslam_handle *h, const pfslam_node **out, int *n)
+{
+    if (!h || !out || !n) return fail("pfslam_get_map: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t K = h->kd_size;
+    if (K) { // topology and positions live in the host mirror; only the weights change on the device
+        h->h_tmp.resize(K);
+        HIPCHK(hipMemcpyAsync(h->h_tmp.data(), h->kw, K * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < K; i++) h->h_nodes[i].w = h->h_tmp[i];
+    }
+    *out = h->h_nodes.data();
+    *n = (int)K;
+    return 0;
+}
+
+extern "C" int pfslam_get_pose(pfslam_handle *h, float pose[3])
+{
+    if (!h || !pose) return fail("pfslam_get_pose: bad argument");
+    float p4[4];
+    HIPCHK(hipMemcpyAsync(p4, h->pose, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(pose, p4, 12);
+    memcpy(h->h_pose, p4, 12);
+    return 0;
+}
+
+extern "C" int pfslam_get_trace(pfslam_handle *h, int32_t out[8])
+{
+    if (!h || !out) return fail("pfslam_get_trace: bad argument");
+    memcpy(out, h->trace, sizeof(h->trace));
+    return 0;
+}
+
+// ---- A3 -------------------------------------------------------------------------------------
+extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_motion, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->w, h->wm,
+                       h->n, frame, h->goff);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- A5 -------------------------------------------------------------------------------------
+static int score_chunks(const pfslam_handle *h)
+{
+    // enough waves to fill 256 CUs x 32 wave slots twice over, never fewer than 8 beams a chunk
+    const int groups = (h->n + 63) / 64;
+    int chunks = (16384 + groups - 1) / groups;
+    chunks = std::max(1, std::min(chunks, (h->nb + 7) / 8));
+    return chunks;
+}
+
+static int launch_score(pfslam_handle *h)
+{
+    if (h->kd_size <= 0) return fail("pfslam_score_kd: no map loaded");
+    const int chunks = score_chunks(h);
+    const int bpc = (h->nb + chunks - 1) / chunks;
+    const int used = (h->nb + bpc - 1) / bpc;
+    float *out = h->fit;
+    if (used > 1) {
+        const size_t need = (size_t)used * h->n;
+        if (need > h->partial_elems) {
+            if (h->partial) HIPCHK(hipFree(h->partial));
+            h->partial = nullptr;
+            CHK(dalloc(&h->partial, need));
+            h->partial_elems = need;
+        }
+        out = h->partial;
+    }
+    dim3 grid((h->n + 255) / 256, used);
+    if (h->planar)
+        hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
+                           bpc, kd_view(h), out);
+    else
+        hipLaunchKernelGGL(k_score_kd<false>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
+                           bpc, kd_view(h), out);
+    HIPCHK(hipGetLastError());
+    if (used > 1) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n,
+                           used, h->fit);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int pfslam_score_kd(pfslam_handle *h, float *fit_host)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(launch_score(h));
+    if (fit_host) {
+        HIPCHK(hipMemcpyAsync(fit_host, h->fit, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch)
+{
+    if (!h || iters <= 0 || !ms_per_launch) return fail("pfslam_time_score_kd: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(launch_score(h)); // warm
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int k = 0; k < iters; k++) CHK(launch_score(h));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_launch = ms / iters;
+    return 0;
+}
+
+extern "C" int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *best_host)
+{
+    if (!h || !xyz_host || !best_host || n < 0) return fail("pfslam_traverse: bad argument");
+    if (h->kd_size <= 0) return fail("pfslam_traverse: no map loaded");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    float *d_xyz = nullptr;
+    int *d_best = nullptr;
+    CHK(dalloc(&d_xyz, (size_t)n * 3));
+    CHK(dalloc(&d_best, (size_t)n));
+    HIPCHK(hipMemcpyAsync(d_xyz, xyz_host, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    bool planar = h->planar;
+    if (planar)
+        for (int i = 0; i < n; i++)
+            if (xyz_host[3 * i + 2] != 0.0f) { planar = false; break; }
+    if (planar)
+        hipLaunchKernelGGL(k_traverse<true>, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_xyz, n, kd_view(h), d_best);
+    else
+        hipLaunchKernelGGL(k_traverse<false>, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_xyz, n, kd_view(h), d_best);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(best_host, d_best, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d_xyz));
+    HIPCHK(hipFree(d_best));
+    return 0;
+}
+
+extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_host, int n, float *out_host)
+{
+    if (!h || !in_host || !out_host || n <= 0) return fail("pfslam_debug_math: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int per = which == 0 ? 2 : 1;
+    float *d_in = nullptr, *d_out = nullptr;
+    CHK(dalloc(&d_in, (size_t)n));
+    CHK(dalloc(&d_out, (size_t)n * per));
+    HIPCHK(hipMemcpyAsync(d_in, in_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, h->stream, which, d_in, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_host, d_out, (size_t)n * per * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d_in));
+    HIPCHK(hipFree(d_out));
+    return 0;
+}
+
+extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes)
+{
+    if (!h || !ptr || !bytes) return fail("pfslam_device_ptr: bad argument");
+    const size_t n = h->n;
+    switch (which) {
+    case 0: *ptr = h->stats; *bytes = 64; break;
+    case 1: *ptr = h->fit; *bytes = n * 4; break;
+    case 2: *ptr = h->x; *bytes = n * 4; break;
+    case 3: *ptr = h->y; *bytes = n * 4; break;
+    case 4: *ptr = h->th; *bytes = n * 4; break;
+    case 5: *ptr = h->w; *bytes = n * 4; break;
+    case 6: *ptr = h->tile_r; *bytes = ((n + PF_SUM_TILE - 1) / PF_SUM_TILE) * 4; break;
+    case 7: *ptr = h->scan; *bytes = (size_t)h->nb * 4; break;
+    case 8: *ptr = h->start; *bytes = 16; break;
+    case 9: *ptr = h->pose; *bytes = 16; break;
+    default: return fail("pfslam_device_ptr: unknown buffer");
+    }
+    return 0;
+}

@@ -1,0 +1,147 @@
+/*
+ * pfslam.h -- C-ABI of libpfslam_hip.so: the MI355X-native particle-filter SLAM
+ * inner loop (disperse -> KD scan-match score -> min/max/argmax + weight
+ * normalise -> single-step ICP/SVD pose -> point-cloud map update -> weighted
+ * resample), the drop-in for the path the reference implements in
+ * src/kernel.cu behind src/kernel.h.
+ *
+ * Plain pointers and sizes only: no C++ types, no torch types.  Every entry
+ * point returns 0 on success, non-zero on failure (pfslam_last_error() gives
+ * the message); nothing in the library calls exit() (the reference does,
+ * kernel.h:42-60).  One handle = one GPU = one host thread.
+ *
+ * Reference interface each entry replaces (file:line under the reference repo):
+ *   pfslam_create / pfslam_destroy     particleFilterInit(Scene*) / particleFilterFree()
+ *                                      + particleFilterInitPC / FreePC    kernel.h:14-15,22-23 (kernel.cu:107-178,1096-1122)
+ *   pfslam_step                        particleFilter(uchar4*, int frame, Lidar*)   kernel.h:16 (kernel.cu:1702-1762)
+ *   pfslam_get_pose/particles/map      getPCData(...)                     kernel.h:19 (kernel.cu:803-813)
+ *   pfslam_motion_update               PFMotionUpdate / kernAddNoise      kernel.cu:375-418
+ *   pfslam_score_kd                    kernEvaluateParticlesKD            kernel.cu:1198-1308
+ *   pfslam_measurement_update          PFMeasurementUpdateKD host logic   kernel.cu:1311-1348
+ *   pfslam_icp                         transformPointICP                  kernel.cu:993-1093
+ *   pfslam_update_map_kd               PFUpdateMapKD                      kernel.cu:1406-1540
+ *   pfslam_resample                    PFResample / kernWeightedSample    kernel.cu:420-511
+ *   pfslam_score_grid/update_map_grid  kernEvaluateParticles / PFUpdateMap kernel.cu:243-372,513-621
+ *   pfslam_kd_create/insert/balance    KDTree::Create/InsertNode/Balance  kdtree.cpp:25-105
+ */
+#ifndef PFSLAM_H
+#define PFSLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* KDTree::Node (kdtree.hpp:16-27): 32 bytes, children/parent are array indices, -1 = none */
+typedef struct pfslam_node {
+    int32_t axis, left, right, parent;
+    float x, y, z, w;
+} pfslam_node;
+
+/* Particle (sceneStructs.h:33-38): 32 bytes, pos@0 (x, y, heading), w@12, cluster@16, map ptr@24 */
+typedef struct pfslam_particle {
+    float x, y, theta, w;
+    uint8_t cluster;
+    uint8_t pad_[7];
+    void *map;
+} pfslam_particle;
+
+typedef struct pfslam_config {
+    int32_t n_particles;   /* PARTICLE_COUNT (kernel.cu:30), runtime here; particles owned by THIS handle */
+    int32_t n_beams;       /* LIDAR_SIZE (kernel.cu:43) = 1081 */
+    float map_scale_x, map_scale_y; /* Patch.scale (data/map_settings.txt: 40 40) */
+    float map_res_x, map_res_y;     /* Patch.resolution (0.025) */
+    int32_t kd_capacity;   /* KD_MAX_SIZE (kernel.cu:77); nodes */
+    int32_t device;        /* HIP device ordinal */
+    int32_t strict_host_mirror; /* 1 = reproduce the half-array weight read-back of kernel.cu:1341 (H11) */
+    int32_t free_upload_bug;    /* 1 = reproduce kernel.cu:1475 (free list tail zero) (H6); 0 = full list */
+    int32_t balance_period;     /* 100 = KDTree::Balance at frame%100==5 (kernel.cu:1707); 0 = never */
+    /* multi-GPU particle sharding: this handle holds global particles [global_offset, global_offset+n_particles)
+     * of global_n; RNG streams are keyed by the GLOBAL index so results do not depend on the sharding. */
+    int32_t global_offset;
+    int32_t global_n;      /* 0 -> n_particles */
+    int32_t reserved_[3];
+} pfslam_config;
+
+typedef struct pfslam_handle pfslam_handle;
+
+/* defaults of the reference: 1081 beams, 40x40 m @ 0.025 m, strict parity flags on */
+void pfslam_default_config(pfslam_config *cfg);
+int pfslam_create(const pfslam_config *cfg, pfslam_handle **out);
+int pfslam_destroy(pfslam_handle *h);
+const char *pfslam_last_error(void);
+/* number of visible HIP devices, or <0 with the HIP error negated */
+int pfslam_device_count(void);
+/* launch on this HIP stream (hipStream_t as void*) instead of the handle's own */
+int pfslam_set_stream(pfslam_handle *h, void *hip_stream);
+int pfslam_synchronize(pfslam_handle *h);
+
+/* ---- whole step (kernel.h:16) ---- */
+int pfslam_step(pfslam_handle *h, int frame, const float *scan_host);
+
+/* ---- read-back (kernel.h:19): non-owning pointers into the handle's host mirrors, valid until the next call */
+int pfslam_get_pose(pfslam_handle *h, float pose[3]);
+int pfslam_get_particles(pfslam_handle *h, const pfslam_particle **out, int *n);
+int pfslam_get_map(pfslam_handle *h, const pfslam_node **out, int *n);
+int pfslam_get_grid(pfslam_handle *h, const int8_t **grid, int *dimx, int *dimy);
+/* per-step trace of the last pfslam_step: [best, resampled, n_wall, n_free, n_insert, neff(float bits), kd_size, 0] */
+int pfslam_get_trace(pfslam_handle *h, int32_t out[8]);
+/* ascending cell indices (x*dimx+y) of the last map update; which: 0 = wall, 1 = free. Returns count via *n. */
+int pfslam_get_cells(pfslam_handle *h, int which, int32_t *out, int cap, int *n);
+
+/* ---- state upload ---- */
+int pfslam_set_map(pfslam_handle *h, const pfslam_node *nodes, int n);
+int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, int n);
+int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_beams);
+int pfslam_set_pose(pfslam_handle *h, const float pose[3]);
+int pfslam_set_grid(pfslam_handle *h, const int8_t *grid, int dimx, int dimy);
+
+/* ---- stage entry points (operate on the handle's device-resident state) ---- */
+int pfslam_motion_update(pfslam_handle *h, int frame);
+/* fit_host may be NULL (result stays on the device; no synchronisation) */
+int pfslam_score_kd(pfslam_handle *h, float *fit_host);
+/* min/max/first-argmax of fit + weight update; outputs may be NULL */
+int pfslam_measurement_update(pfslam_handle *h, int *best, float *fmin, float *fmax);
+/* ICP around the handle's current pose (the PREVIOUS robotPos, kernel.cu:1013) from `start`; dbg29 optional:
+ * A[9], mu_tar[3], mu_cor[3], R[9], t[3], theta, n_valid */
+int pfslam_icp(pfslam_handle *h, const float start[3], float pose_out[3], float *dbg29);
+int pfslam_update_map_kd(pfslam_handle *h);
+int pfslam_resample(pfslam_handle *h, int frame, int *resampled, float *neff);
+int pfslam_score_grid(pfslam_handle *h, int32_t *fit_host);
+int pfslam_update_map_grid(pfslam_handle *h);
+
+/* batch KD "nearest neighbour" with the reference traversal (findCorrespondenceIndexKD, kernel.cu:924-972);
+ * xyz_host: n*3 floats; best_host: n ints */
+int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *best_host);
+
+/* ---- multi-GPU merge hooks (particles sharded over ranks; collectives are the caller's, e.g. RCCL) ----
+ * stats layout (device, 8 x int64): [0] max key, [1] negated-min key (both to be all-reduced with MAX),
+ * rest reserved.  key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index).            */
+int pfslam_measurement_local(pfslam_handle *h);  /* score must have run; fills the stats buffer */
+int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, float *fmax); /* after the all-reduce */
+/* device pointers of the handle's buffers, for zero-copy wrapping by the harness.
+ * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta, 5 w (n x f32 each), 6 weight tile sums,
+ *        7 scan (n_beams x f32) */
+int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
+
+/* ---- bench support: time `iters` back-to-back launches of the score kernel with HIP events on the
+ * handle's stream; returns the average milliseconds per launch ---- */
+int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
+/* which scoring kernel variant to run: 0 = auto, 1 = global-memory nodes, 2 = LDS-staged tree top */
+int pfslam_set_variant(pfslam_handle *h, int variant);
+
+/* ---- debug: evaluate the bit-reproducible math specification (pf_math.h) on the device.
+ * which: 0 sincos (out: n x {sin, cos}), 1 erfcinv, 2 asin, 3 rsqrt, 4 sqrt_rn, 5 x / 0.025f ---- */
+int pfslam_debug_math(pfslam_handle *h, int which, const float *in_host, int n, float *out_host);
+
+/* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
+int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);
+int pfslam_kd_insert_node(const float p[4], pfslam_node *list, int list_size);
+int pfslam_kd_balance(pfslam_node *list, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,161 @@
+/*
+ * pfslam_oracle.h -- CPU oracle for the particle-filter SLAM hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithm in
+ * the reference's src/kernel.cu (+ kdtree.cpp, svd3.h, utilities.cpp); it is the
+ * checker the parity tests compare the HIP path against.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (gpu-icp-slam_amd/) never includes, links or calls anything in oracle/.
+ *
+ * Parity pinning status (see DESIGN.md "Oracle"):
+ *   - KD-tree Create/Balance/InsertNode: PINNED against the reference's own
+ *     src/kdtree.cpp compiled unmodified into oracle/_ref/libkdtree_ref.so.
+ *   - RNG (minstd_rand / uniform_real / normal via erfcinv): PINNED against the
+ *     image's rocThrust headers compiled for the host (oracle/_ref/thrust_probe);
+ *     thrust itself is a dependency absent from /root/reference (CUDA 7.5 toolkit).
+ *   - Everything that only the CUDA device could execute (traversal, scoring,
+ *     ICP kernels, map update, resample): PARITY UNPINNED -- the reference has no
+ *     tests / golden vectors and cannot be built or run here (nvcc, libmat, PCL,
+ *     GL all absent).  The restatement follows the cited lines literally; the
+ *     undefined behaviours H1..H11 are given the definitions in DESIGN.md.
+ *
+ * Arithmetic contract: IEEE-754 binary32, one rounding per source-level
+ * operation, no FMA contraction (built with -ffp-contract=off), sqrt and divide
+ * correctly rounded.  Transcendentals (cos/sin, erfcinv, log, asin) follow the
+ * "pf_math" specification below: fixed sequences of IEEE double operations, so
+ * that the CPU oracle and the gfx950 kernels produce identical bits.
+ */
+#ifndef PFSLAM_ORACLE_H
+#define PFSLAM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* KDTree::Node, reference src/kdtree.hpp:16-27 (32 bytes, align 4) */
+typedef struct {
+    int32_t axis, left, right, parent;
+    float x, y, z, w;
+} orc_node;
+
+/* Particle, reference src/sceneStructs.h:33-38 (32 bytes: vec3 pos@0, w@12, cluster@16, ptr@24) */
+typedef struct {
+    float x, y, theta, w;
+    uint8_t cluster;
+    uint8_t pad_[7];
+    uint64_t map;
+} orc_particle;
+
+/* the parts of Patch (sceneStructs.h:40-45) the hot path reads */
+typedef struct {
+    float scale_x, scale_y;
+    float res_x, res_y;
+} orc_patch;
+
+#define ORC_LIDAR_SIZE 1081 /* kernel.cu:43 */
+
+/* ---- A2: RNG (kernel.cu:89-102 + thrust::minstd_rand) ---- */
+uint32_t orc_utilhash(uint32_t a);
+uint32_t orc_engine_seed(int iter, int index, int depth);
+uint32_t orc_minstd_next(uint32_t *state);
+float orc_uniform_real(uint32_t *state, float a, float b);
+float orc_normal(uint32_t *state, float mean, float stddev);
+
+/* ---- pf_math specification (bit-reproducible transcendentals) ---- */
+void orc_sincosf(float x, float *s, float *c);
+double orc_log(double x);
+double orc_ndtri(double y0);
+float orc_erfcinvf(float y);
+float orc_asinf(float x);
+float orc_rsqrtf(float x);
+/* canonical reduction order standing in for thrust::reduce (order unspecified) */
+float orc_sum_f32(const float *v, int n, int stride);
+/* canonical inclusive scan standing in for thrust::inclusive_scan */
+void orc_inclusive_scan_f32(const float *w, int n, float *cdf);
+
+/* ---- A3: motion / dispersion (kernel.cu:375-397) ---- */
+void orc_add_noise(orc_particle *p, int n, int frame, int global_idx0);
+
+/* ---- A4/A5: scan match against the KD map (kernel.cu:182-187, 1198-1308) ---- */
+void orc_clean_lidar_scan(int n, float scan, float theta, float *x, float *y);
+int orc_kd_traverse(const orc_node *tree, float px, float py, float pz, int *visits);
+void orc_score_kd(const orc_node *tree, const orc_particle *p, int n, const float *scan,
+                  int n_beams, float *fit, uint64_t *node_visits, uint64_t *valid_beams);
+void orc_score_kd_mt(const orc_node *tree, const orc_particle *p, int n, const float *scan,
+                     int n_beams, float *fit, int n_threads);
+void orc_traverse_batch(const orc_node *tree, const float *xyz, int n, int32_t *best, int32_t *visits);
+
+/* ---- A6: min/max/argmax + weight update (kernel.cu:297-304, 1327-1338) ---- */
+void orc_minmax_first_f32(const float *v, int n, int *imin, int *imax);
+void orc_minmax_first_i32(const int32_t *v, int n, int *imin, int *imax);
+void orc_update_weights_f32(orc_particle *p, int n, const float *fit, float c, int min_trunc);
+void orc_update_weights_i32(orc_particle *p, int n, const int32_t *fit, float c, int min_v);
+
+/* ---- A7-A9: single-step ICP (kernel.cu:974-1093, svd3.h:354-401) ---- */
+void orc_svd3(const float a[9], float u[9], float s[9], float v[9]);
+/* dbg (optional, 31 floats): W[9] (a11..a33 as passed to svd), mu_tar[3], mu_cor[3], R[9] (glm col-major), t[3], theta, n_valid(as float),pad */
+void orc_icp(const orc_node *tree, const float robot[3], const float start[3], const float *scan,
+             int n_beams, float out_pose[3], float *dbg);
+
+/* ---- A10: Bresenham free-cell raycast (kernel.cu:190-240, 524-549) ---- */
+void orc_trace_ray(int sx, int sy, int ex, int ey, int dimx, int dimy, uint8_t *out);
+void orc_get_walls(const float *scan, int n_beams, int cx, int cy, float theta, uint8_t *free_mask,
+                   uint8_t *wall_mask, int dimx, int dimy, float res_x, float res_y);
+
+/* ---- A11-A15: point-cloud map update (kernel.cu:1350-1540, kdtree.cpp:25-105) ---- */
+/* masks -> world-coordinate point lists, x-major order (kernel.cu:1435-1461).  Returns counts. */
+void orc_masks_to_points(const uint8_t *free_mask, const uint8_t *wall_mask, int dimx, int dimy,
+                         const orc_patch *patch, const float robot[3], float *wall_xyzw,
+                         int *n_wall, float *free_xyzw, int *n_free);
+void orc_update_map_kd(orc_node *tree, const float *pts_xyzw, const int32_t *idx, int n, int val,
+                       const orc_patch *patch);
+void orc_test_correspondence(const orc_node *tree, const float *pts_xyzw, const int32_t *idx, int n,
+                             uint8_t *create, const orc_patch *patch);
+void orc_kd_insert_node(const float p[4], orc_node *list, int list_size);
+/* implemented in kdtree_oracle.cpp (needs std::sort) */
+void orc_kd_create(const float *pts_xyzw, int n, orc_node *list);
+void orc_kd_balance(orc_node *list, int n);
+
+/* ---- A16: resample (kernel.cu:420-511) ---- */
+/* returns 1 if resampled; src_idx (optional, n ints) receives the chosen source per slot */
+int orc_resample(orc_particle *p, int n, int frame, float *neff_out, int32_t *src_idx);
+void orc_weighted_sample_indices(const float *cdf, int n, float neff, int frame, int i0, int count,
+                                 int32_t *src_idx);
+
+/* ---- A17/A18: 2-D occupancy grid path (kernel.cu:243-372, 513-621) ---- */
+void orc_score_grid(const int8_t *grid, int dimx, int dimy, const orc_patch *patch,
+                    const orc_particle *p, int n, const float *scan, int n_beams, int32_t *fit);
+void orc_update_map_grid(int8_t *grid, int dimx, int dimy, const orc_patch *patch,
+                         const float robot[3], const float *scan, int n_beams);
+
+/* ---- whole SLAM step (kernel.cu:1702-1762), KD / point-cloud path ---- */
+typedef struct orc_slam orc_slam;
+typedef struct {
+    int n_particles;
+    int n_beams;         /* 1081 */
+    orc_patch patch;     /* 40 x 40 m, 0.025 m */
+    int kd_capacity;
+    int strict_host_mirror; /* H11: reproduce the half-array D2H at kernel.cu:1341 */
+    int free_upload_bug;    /* H6: 0 = upload full free list, 1 = zero tail past wallPC.size() */
+    int balance_period;     /* 100 (kernel.cu:1707); 0 disables */
+} orc_slam_config;
+
+orc_slam *orc_slam_create(const orc_slam_config *cfg);
+void orc_slam_destroy(orc_slam *s);
+void orc_slam_set_map(orc_slam *s, const orc_node *tree, int n);
+void orc_slam_step(orc_slam *s, int frame, const float *scan);
+void orc_slam_get_pose(const orc_slam *s, float pose[3]);
+int orc_slam_kd_size(const orc_slam *s);
+const orc_node *orc_slam_tree(const orc_slam *s);
+const orc_particle *orc_slam_particles(const orc_slam *s);
+/* per-step trace of the last orc_slam_step: best idx, resampled flag, n_wall, n_free, n_insert, neff(float bits) */
+void orc_slam_last_trace(const orc_slam *s, int32_t out[8]);
+/* wall/free cell index lists (x*dimx+y, ascending) of the last step */
+int orc_slam_last_cells(const orc_slam *s, int which /*0 wall,1 free*/, int32_t *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,42 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/pfslam.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pfslam.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfslam_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.load()
+    names = declared_symbols()
+    assert len(names) >= 35
+    for name in names:
+        assert hasattr(L, name), "libpfslam_hip.so does not export %s" % name
+    assert set(pkg.binding.SYMBOLS) == set(names)
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback(pkg):
+    if pkg.device_count() > 0:
+        return  # on the GPU box this is covered by the gpu tests
+    try:
+        pkg.PfSlam(64)
+    except pkg.PfSlamError as e:
+        assert "no HIP device" in str(e) or "hip" in str(e).lower()
+    else:
+        raise AssertionError("creating a handle without a GPU must fail")
+
+
+def test_struct_layouts_match_reference(pkg):
+    # KDTree::Node 32 B (kdtree.hpp:16-27), Particle 32 B with w@12, cluster@16, map@24 (sceneStructs.h:33-38)
+    assert pkg.NODE_DTYPE.itemsize == 32
+    assert pkg.PARTICLE_DTYPE.itemsize == 32
+    assert pkg.PARTICLE_DTYPE.fields["w"][1] == 12
+    assert pkg.PARTICLE_DTYPE.fields["cluster"][1] == 16
+    assert pkg.PARTICLE_DTYPE.fields["map"][1] == 24
+    assert ctypes.sizeof(pkg.Config) == 64

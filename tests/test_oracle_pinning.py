@@ -1,0 +1,196 @@
+"""Pin the CPU oracle (and the product's host-side tree code) against what can be run of the
+reference in this container: its own kdtree.cpp (oracle/_ref/libkdtree_ref.so), the image's
+rocThrust for the RNG, and libm for the transcendentals."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def grid_points(n, seed, span=400):
+    rng = np.random.RandomState(seed)
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = rng.randint(-span, span, n).astype(np.float32) * np.float32(0.025)
+    pts[:, 1] = rng.randint(-span, span, n).astype(np.float32) * np.float32(0.025)
+    pts[:, 3] = rng.randint(-100, 114, n)
+    return pts
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (3, 2), (17, 3), (1000, 4), (5000, 5)])
+def test_kd_create_matches_reference_kdtree_cpp(pkg, oracle, n, seed):
+    ref = O.ref_kdtree()
+    if ref is None:
+        pytest.skip("oracle/_ref/libkdtree_ref.so not built (needs /root/reference)")
+    assert ref.ref_node_size() == 32
+    pts = grid_points(n, seed, span=60)  # heavy key ties: the case std::sort's instability matters
+    want = np.zeros(n, O.NODE_DTYPE)
+    ref.ref_kd_create(O.P(pts), n, O.P(want))
+    got_oracle = O.kd_create(pts)
+    got_product = pkg.kd_create(pts)
+    assert got_oracle.tobytes() == want.tobytes()
+    assert got_product.tobytes() == want.tobytes()
+
+
+def test_kd_create_3d_points_match_reference(pkg, oracle):
+    ref = O.ref_kdtree()
+    if ref is None:
+        pytest.skip("no _ref")
+    rng = np.random.RandomState(9)
+    pts = rng.uniform(-5, 5, (777, 4)).astype(np.float32)
+    want = np.zeros(len(pts), O.NODE_DTYPE)
+    ref.ref_kd_create(O.P(pts), len(pts), O.P(want))
+    assert O.kd_create(pts).tobytes() == want.tobytes()
+    assert pkg.kd_create(pts).tobytes() == want.tobytes()
+
+
+def test_kd_insert_and_balance_match_reference(pkg, oracle):
+    ref = O.ref_kdtree()
+    if ref is None:
+        pytest.skip("no _ref")
+    base = grid_points(500, 21, span=80)
+    extra = grid_points(300, 22, span=80)
+    extra[:, 3] = -100
+    cap = 800
+    trees = []
+    for kind in ("ref", "oracle", "product"):
+        t = np.zeros(cap, O.NODE_DTYPE)
+        if kind == "ref":
+            ref.ref_kd_create(O.P(base), 500, O.P(t))
+            for k in range(300):
+                ref.ref_kd_insert_node(O.P(extra[k]), O.P(t), 500 + k)
+        elif kind == "oracle":
+            O.lib().orc_kd_create(O.P(base), 500, O.P(t))
+            for k in range(300):
+                O.kd_insert(t, 500 + k, extra[k])
+        else:
+            t[:500] = pkg.kd_create(base)
+            for k in range(300):
+                pkg.kd_insert_node(t, 500 + k, extra[k])
+        trees.append(t.copy())
+    assert trees[1].tobytes() == trees[0].tobytes()
+    assert trees[2].tobytes() == trees[0].tobytes()
+    # Balance = rebuild from the current values (kdtree.cpp:31-40)
+    a, b, c = trees[0].copy(), trees[1].copy(), trees[2].copy()
+    ref.ref_kd_balance(O.P(a), cap)
+    O.lib().orc_kd_balance(O.P(b), cap)
+    pkg.kd_balance(c, cap)
+    assert b.tobytes() == a.tobytes()
+    assert c.tobytes() == a.tobytes()
+
+
+def test_tree_invariants(pkg):
+    pts = grid_points(3000, 31)
+    t = pkg.kd_create(pts)
+    n = len(t)
+    assert t["parent"][0] == -1 and t["axis"][0] == 0
+    for i in range(n):
+        for side in ("left", "right"):
+            c = t[side][i]
+            if c >= 0:
+                assert t["parent"][c] == i
+                assert t["axis"][c] == (t["axis"][i] + 1) % 3
+        if t["left"][i] >= 0:
+            assert t["left"][i] == i + 1  # pre-order layout
+    # every input point appears exactly once
+    got = np.sort(np.stack([t["x"], t["y"], t["z"], t["w"]], 1).view("f4,f4,f4,f4").ravel())
+    want = np.sort(pts.view("f4,f4,f4,f4").ravel())
+    assert (got == want).all()
+
+
+def test_minstd_and_uniform_match_rocthrust(oracle):
+    T = O.thrust_probe()
+    if T is None:
+        pytest.skip("thrust probe not built")
+    L = O.lib()
+    for seed in (1, 12345, 2147483646, 2147483647, 0, 4000000000):
+        out = np.zeros(64, np.uint32)
+        T.tp_minstd(C.c_uint(seed), 64, O.P(out))
+        s = seed % 2147483647 or 1
+        st = C.c_uint32(s)
+        mine = [L.orc_minstd_next(C.byref(st)) for _ in range(64)]
+        assert mine == out.tolist()
+    assert L.orc_minstd_next(C.byref(C.c_uint32(12345))) == 595905495  # SURVEY.md 8c known answer
+    o = np.zeros(500, np.float32)
+    T.tp_uniform(777, 0.0, 3.5, 500, O.P(o))
+    st = C.c_uint32(777)
+    mine = np.array([L.orc_uniform_real(C.byref(st), 0.0, 3.5) for _ in range(500)], np.float32)
+    assert (mine == o).all()
+
+
+def test_normal_distribution_structure_matches_rocthrust(oracle):
+    """rocThrust evaluates mean + sd*S3*erfcinv(2p) with a double erfcinv (Cephes ndtri); replaying that
+    with the oracle's ndtri/log restatement must reproduce its samples exactly, and the oracle's own
+    (CUDA-like, float erfcinv) samples must agree to 1 ulp."""
+    T = O.thrust_probe()
+    if T is None:
+        pytest.skip("thrust probe not built")
+    L = O.lib()
+    S1, S2 = np.float32(2.0 ** -31), np.float32(2.0 ** -32)
+    sds = (np.float32(0.015), np.float32(0.015), np.float32(0.01))
+    worst = 0
+    for k in range(3000):
+        seed = L.orc_engine_seed(k % 97 + 1, k, 0)
+        o = np.zeros(3, np.float32)
+        T.tp_normal3(seed, 0.015, 0.015, 0.01, O.P(o))
+        st = C.c_uint32(seed)
+        st2 = C.c_uint32(seed)
+        for j, sd in enumerate(sds):
+            u = L.orc_minstd_next(C.byref(st)) - 1
+            S3 = np.float32(-1.4142135623730950488)
+            if u > 2147483645 // 2:
+                u = 2147483645 - u
+                S3 = -S3
+            p = np.float32(np.float32(u) * S1 + S2)
+            e = -L.orc_ndtri(0.5 * float(np.float32(2) * p)) * (1 / math.sqrt(2.0))
+            assert np.float32(float(np.float32(sd * S3)) * e) == o[j]
+            mine = np.float32(L.orc_normal(C.byref(st2), 0.0, float(sd)))
+            worst = max(worst, abs(int(mine.view(np.int32)) - int(o[j].view(np.int32))))
+    assert worst <= 1
+
+
+def test_transcendentals_are_correctly_rounded_and_close_to_libm(oracle):
+    L = O.lib()
+    m = C.CDLL("libm.so.6")
+    for f in ("sinf", "cosf", "asinf"):
+        getattr(m, f).restype = C.c_float
+        getattr(m, f).argtypes = [C.c_float]
+    x = np.random.RandomState(0).uniform(-8, 8, 20000).astype(np.float32)
+    s, c = O.sincosf(x)
+    assert (s == np.sin(x.astype(np.float64)).astype(np.float32)).all()
+    assert (c == np.cos(x.astype(np.float64)).astype(np.float32)).all()
+    gs = np.array([m.sinf(float(v)) for v in x], np.float32)
+    gc = np.array([m.cosf(float(v)) for v in x], np.float32)
+    ulp = lambda a, b: np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    assert ulp(s, gs).max() <= 1 and ulp(c, gc).max() <= 1
+    assert (s != gs).mean() < 0.03 and (c != gc).mean() < 0.03
+    xa = np.random.RandomState(2).uniform(-1, 1, 20000).astype(np.float32)
+    a = np.array([L.orc_asinf(float(v)) for v in xa], np.float32)
+    assert (a == np.arcsin(xa.astype(np.float64)).astype(np.float32)).all()
+    for v in np.random.RandomState(3).uniform(1e-12, 50, 5000):
+        assert abs(L.orc_log(float(v)) - math.log(v)) <= 4e-16 * max(1.0, abs(math.log(v)))
+
+
+def test_utilhash_and_seed_known_answers(oracle):
+    L = O.lib()
+
+    def utilhash(a):
+        M = 0xFFFFFFFF
+        a = ((a + 0x7ed55d16) + (a << 12)) & M
+        a = ((a ^ 0xc761c23c) ^ (a >> 19)) & M
+        a = ((a + 0x165667b1) + (a << 5)) & M
+        a = ((a + 0xd3a2646c) ^ (a << 9)) & M
+        a = ((a + 0xfd7046c5) + (a << 3)) & M
+        a = ((a ^ 0xb55a4f09) ^ (a >> 16)) & M
+        return a
+
+    for a in (0, 1, 12345, 0x80000001, 0xFFFFFFFF):
+        assert L.orc_utilhash(a) == utilhash(a)
+    for it, idx, dep in ((1, 0, 0), (7, 999, 0), (650, 3, 5), (650, 3, 5 + 512), (650, 3, 5 + 1024)):
+        key = (0x80000000 | ((dep << 22) & 0xFFFFFFFF) | it) & 0xFFFFFFFF
+        h = utilhash(key) ^ utilhash(idx)
+        assert L.orc_engine_seed(it, idx, dep) == (h % 2147483647 or 1)
+    # H5: the thread index only contributes its low 9 bits (bit 31 is forced by 1 << 31)
+    assert L.orc_engine_seed(650, 3, 5) == L.orc_engine_seed(650, 3, 5 + 512) == L.orc_engine_seed(650, 3, 5 + 1024)

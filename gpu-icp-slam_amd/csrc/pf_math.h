@@ -16,22 +16,11 @@
 
 namespace pf {
 
-PF_HD float fsqrt(float x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return sqrtf(x);
-#endif
-}
-PF_HD float fdiv(float a, float b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fdiv_rn(a, b);
-#else
-    return a / b;
-#endif
-}
+// IEEE correctly rounded sqrt / divide.  NOT __fsqrt_rn: on ROCm that intrinsic lowers to the
+// native (1 ulp) v_sqrt_f32.  Plain sqrtf / operator/ are correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt (checked bit-for-bit on gfx950 by tests/test_gpu_score.py).
+PF_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
+PF_HD float fdiv(float a, float b) { return a / b; }
 
 // sin and cos of a float argument: Cody-Waite reduction by pi/2 (33+53-bit constants,
 // exact for |x| < 1e6), fdlibm kernel polynomials, all in double with explicit fma.

@@ -212,8 +212,6 @@ __global__ void k_debug_math(int which, const float *__restrict__ in, int n, flo
     }
 }
 
-#include "pfslam_stages.hip.inc"
-
 // ==========================================================================================
 // C-ABI
 // ==========================================================================================
@@ -640,3 +638,5 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
     }
     return 0;
 }
+
+#include "pfslam_stages.hip.inc"

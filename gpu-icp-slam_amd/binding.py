@@ -23,7 +23,7 @@ SYMBOLS = [
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
-    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math",
+    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers",
 ]
 
 
@@ -95,6 +95,8 @@ def load():
     L.pfslam_kd_insert_node.argtypes = [vp, vp, i32]
     L.pfslam_kd_balance.argtypes = [vp, i32]
     L.pfslam_debug_math.argtypes = [vp, i32, vp, i32, vp]
+    L.pfslam_set_timing.argtypes = [vp, i32]
+    L.pfslam_get_timers.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -183,6 +185,14 @@ class PfSlam:
 
     def set_variant(self, v):
         _chk(self.L.pfslam_set_variant(self._h, v), "pfslam_set_variant")
+
+    def set_timing(self, enable):
+        _chk(self.L.pfslam_set_timing(self._h, int(enable)), "pfslam_set_timing")
+
+    def timers(self):
+        out = (C.c_double * 4)()
+        _chk(self.L.pfslam_get_timers(self._h, out), "pfslam_get_timers")
+        return {"score_ms": out[0], "score_launches": int(out[1])}
 
     def synchronize(self):
         _chk(self.L.pfslam_synchronize(self._h), "pfslam_synchronize")

@@ -111,6 +111,11 @@ struct pfslam_handle {
     std::vector<float4> h_new;
     int32_t trace[8] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // live timing of the dominant kernel inside pfslam_step (bench.py roofline leg)
+    int timing = 0;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    double score_ms = 0.0;
+    long score_launches = 0;
 };
 
 // ==========================================================================================
@@ -274,6 +279,8 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     h->own_stream = true;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipEventCreate(&h->tev0));
+    HIPCHK(hipEventCreate(&h->tev1));
     const size_t n = h->n, M = (size_t)h->dimx * h->dimy;
     CHK(dalloc(&h->x, n)); CHK(dalloc(&h->y, n)); CHK(dalloc(&h->th, n)); CHK(dalloc(&h->w, n)); CHK(dalloc(&h->wm, n));
     CHK(dalloc(&h->x2, n)); CHK(dalloc(&h->y2, n)); CHK(dalloc(&h->th2, n));
@@ -332,6 +339,8 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->h_hdr) (void)hipHostFree(h->h_hdr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->tev0) (void)hipEventDestroy(h->tev0);
+    if (h->tev1) (void)hipEventDestroy(h->tev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -353,6 +362,23 @@ extern "C" int pfslam_synchronize(pfslam_handle *h)
 {
     if (!h) return fail("null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pfslam_set_timing(pfslam_handle *h, int enable)
+{
+    if (!h) return fail("null handle");
+    h->timing = enable;
+    h->score_ms = 0.0;
+    h->score_launches = 0;
+    return 0;
+}
+extern "C" int pfslam_get_timers(pfslam_handle *h, double out[4])
+{
+    if (!h || !out) return fail("pfslam_get_timers: bad argument");
+    out[0] = h->score_ms;
+    out[1] = (double)h->score_launches;
+    out[2] = out[3] = 0.0;
     return 0;
 }
 

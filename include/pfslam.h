@@ -129,6 +129,10 @@ int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
 /* ---- bench support: time `iters` back-to-back launches of the score kernel with HIP events on the
  * handle's stream; returns the average milliseconds per launch ---- */
 int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
+/* live timing of the scan-match kernel inside pfslam_step: HIP events on the handle's stream bracket every
+ * launch; pfslam_get_timers -> [total ms, launches, 0, 0].  pfslam_set_timing also resets the accumulators. */
+int pfslam_set_timing(pfslam_handle *h, int enable);
+int pfslam_get_timers(pfslam_handle *h, double out[4]);
 /* which scoring kernel variant to run: 0 = auto, 1 = global-memory nodes, 2 = LDS-staged tree top */
 int pfslam_set_variant(pfslam_handle *h, int variant);
 

@@ -8,6 +8,10 @@
 #pragma once
 #include "pf_math.h"
 
+#ifndef PF_LAZY_SQRT
+#define PF_LAZY_SQRT 2
+#endif
+
 namespace pf {
 
 struct KdView {
@@ -38,9 +42,8 @@ __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, i
 // the sibling side.  It is NOT an exact nearest-neighbour search and is reproduced as is.
 //
 // Distances follow glm::distance: sqrt((dx*dx + dy*dy) + dz*dz), one rounding per operation.
-// sqrt is monotone, so `d < bestDist` can only hold when the squared sum is below the best
-// squared sum; the correctly rounded sqrt is evaluated only then (a handful of times per query
-// instead of once per visited node) and the comparison itself is still made on the rooted values.
+// The per-visit `d < bestDist` is decided on the squared sums with a guard band (see the loop); the
+// rooted best distance is only materialised once per descent, for the parent-hyperplane test.
 //
 // PLANAR: every node has z == 0 and the query has z == 0 (the SLAM map is 2-D): the z term is an
 // exact +0, z-axis levels always branch right and have hyperplane distance 0.
@@ -48,75 +51,71 @@ __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, i
 template <bool PLANAR>
 __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz)
 {
-    uint4 nd = t.hot[0];
-    float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y), nz = 0.0f;
-    float dx = nx - px, dy = ny - py;
-    float s = dx * dx + dy * dy;
-    if (!PLANAR) {
-        nz = t.z[0];
-        float dz = nz - pz;
-        s = s + dz * dz;
-    }
-    float sBest = s;
-    float bestDist = fsqrt(s);
-    int bestIdx = 0;
-    bool explored = false;
-    int head = 0;
+    // bestDist starts as the distance to the root; visiting the root first reproduces that state
+    float sBest = INFINITY, sGuard = INFINITY;
+    int bestIdx = 0, prevBest = -1, head = 0;
     for (;;) {
-        while (head >= 0) {
-            nd = t.hot[head];
-            nx = __uint_as_float(nd.x);
-            ny = __uint_as_float(nd.y);
-            dx = nx - px;
-            dy = ny - py;
-            s = dx * dx + dy * dy;
+        while (head >= 0) { // greedy descent
+            const uint4 nd = t.hot[head];
+            const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+            const float dx = nx - px, dy = ny - py;
+            float s = dx * dx + dy * dy;
+            float nz = 0.0f;
             if (!PLANAR) {
                 nz = t.z[head];
-                float dz = nz - pz;
+                const float dz = nz - pz;
                 s = s + dz * dz;
             }
-            if (s < sBest) {
-                float d = fsqrt(s);
-                if (d < bestDist) {
-                    bestDist = d;
-                    sBest = s;
-                    bestIdx = head;
-                    explored = false;
-                }
+            // d < bestDist, decided without a sqrt: if s is below sBest by more than a guard band of 2^-21
+            // (relative), the correctly rounded roots differ for certain (sqrt_rn has relative error <= 2^-24 and
+            // halves relative gaps); only inside the band -- ~1e-6 of visits -- are the two roots compared.
+            bool take = s < sGuard;
+            const bool inBand = (s < sBest) & !take;
+            if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) { // wave-uniform, almost never taken
+                float sb = sBest;
+                asm volatile("" : "+v"(sb)); // pins the two sqrt inside the branch (the compiler would speculate them)
+                take = take | (inBand && fsqrt(s) < fsqrt(sb));
             }
+            sBest = take ? s : sBest;
+            sGuard = take ? (s > 1e-30f ? s * 0.999999523162841796875f : 0.0f) : sGuard;
+            bestIdx = take ? head : bestIdx;
             const uint32_t axis = nd.z >> 30;
-            const bool br = axis == 0 ? (px < nx) : axis == 1 ? (py < ny) : (PLANAR ? false : (pz < nz));
-            head = br ? (int)(nd.z & 0x3fffffffu) - 1 : (int)nd.w;
+            float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;
+            bool lt;
+            if (PLANAR) {
+                lt = (pa < na) & (axis < 2); // z levels: 0 < 0 is false -> right
+            } else {
+                pa = axis == 2 ? pz : pa;
+                na = axis == 2 ? nz : na;
+                lt = pa < na;
+            }
+            head = lt ? (int)(nd.z & 0x3fffffffu) - 1 : (int)nd.w;
         }
-        if (explored) break;
+        // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
+        if (bestIdx == prevBest) break;
+        prevBest = bestIdx;
+        const float bestDist = fsqrt(sBest);
         const int pi = t.parent[bestIdx];
-        if (pi < 0) break;
-        nd = t.hot[pi];
-        nx = __uint_as_float(nd.x);
-        ny = __uint_as_float(nd.y);
+        if (pi < 0) break; // H1
+        const uint4 nd = t.hot[pi];
+        const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
         const uint32_t axis = nd.z >> 30;
+        float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;
         float hd;
-        bool br;
-        if (axis == 0) {
-            br = px < nx;
-            hd = fabsf(px - nx);
-        } else if (axis == 1) {
-            br = py < ny;
-            hd = fabsf(py - ny);
-        } else if (PLANAR) {
-            br = false;
-            hd = 0.0f;
+        bool lt;
+        if (PLANAR) {
+            hd = axis < 2 ? fabsf(pa - na) : 0.0f;
+            lt = (pa < na) & (axis < 2);
         } else {
-            nz = t.z[pi];
-            br = pz < nz;
-            hd = fabsf(pz - nz);
+            if (axis == 2) {
+                pa = pz;
+                na = t.z[pi];
+            }
+            hd = fabsf(pa - na);
+            lt = pa < na;
         }
-        if (hd < bestDist) {
-            head = !br ? (int)(nd.z & 0x3fffffffu) - 1 : (int)nd.w;
-            explored = true;
-        } else {
-            break;
-        }
+        if (!(hd < bestDist)) break;
+        head = lt ? (int)nd.w : (int)(nd.z & 0x3fffffffu) - 1; // the side the query is NOT on
     }
     return bestIdx;
 }

@@ -30,6 +30,9 @@
 #define PF_SCAN_TILE 1024
 #define PF_SCAN_CHUNK 16
 
+extern "C" int pfslam_sort_pairs_u32(void *tmp, size_t *tmp_bytes, const unsigned *keys_in, unsigned *keys_out,
+                                     const int *vals_in, int *vals_out, int n, int end_bit, void *stream);
+
 static thread_local std::string g_err;
 static int fail(const std::string &m)
 {
@@ -80,6 +83,11 @@ struct pfslam_handle {
     // scoring
     float *fit = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
+    // Morton processing order of the particles (performance only; results do not depend on it)
+    unsigned *mkey = nullptr, *mkey2 = nullptr;
+    int *order = nullptr, *order2 = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
     int64_t *stats = nullptr;
     float *pose = nullptr;  // device robotPos[4]
     float *start = nullptr; // device best-particle pose [4]
@@ -153,12 +161,15 @@ template <bool PLANAR>
 __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, const float *__restrict__ py,
                                                   const float *__restrict__ pth, int n,
                                                   const float *__restrict__ scan, int nb, int beams_per_chunk,
-                                                  pf::KdView tree, float *__restrict__ out)
+                                                  pf::KdView tree, const int *__restrict__ order, int direct,
+                                                  float *__restrict__ out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
     const int j0 = blockIdx.y * beams_per_chunk;
     const int j1 = min(nb, j0 + beams_per_chunk);
-    if (i >= n) return;
+    if (slot >= n) return;
+    // lane -> particle through the Morton order: the 64 lanes of a wave hold neighbouring poses
+    const int i = order ? order[slot] : slot;
     const float x = px[i], y = py[i], th = pth[i];
     float acc = 0.0f;
     for (int j = j0; j < j1; j++) {
@@ -171,17 +182,42 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
             acc += tree.w[b];
         }
     }
-    out[(size_t)blockIdx.y * n + i] = acc;
+    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
 }
 
+// beam-chunk partials -> fit, undoing the processing order.  Map weights are integers by construction
+// (0 / -100 initial, -1 / +4 steps, clamp +-113), so the chunked sum equals the reference's sequential one.
 __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ partial, int n, int chunks,
-                                                         float *__restrict__ fit)
+                                                         const int *__restrict__ order, float *__restrict__ fit)
 {
-    int i = blockIdx.x * 256 + threadIdx.x;
+    int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n) return;
+    float a = partial[slot];
+    for (int c = 1; c < chunks; c++) a += partial[(size_t)c * n + slot];
+    fit[order ? order[slot] : slot] = a;
+}
+
+// 30-bit Morton key of (heading, x, y) relative to the current robot pose: 1 mrad / 2 mm cells
+__device__ __forceinline__ unsigned spread10(unsigned v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ x, const float *__restrict__ y,
+                                                     const float *__restrict__ th, int n, const float *__restrict__ pose,
+                                                     unsigned *__restrict__ key, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float a = partial[i];
-    for (int c = 1; c < chunks; c++) a += partial[(size_t)c * n + i];
-    fit[i] = a;
+    const float qx = fminf(fmaxf((x[i] - pose[0]) * 500.0f + 512.0f, 0.0f), 1023.0f);
+    const float qy = fminf(fmaxf((y[i] - pose[1]) * 500.0f + 512.0f, 0.0f), 1023.0f);
+    const float qt = fminf(fmaxf((th[i] - pose[2]) * 1000.0f + 512.0f, 0.0f), 1023.0f);
+    key[i] = (spread10((unsigned)qt) << 2) | (spread10((unsigned)qx) << 1) | spread10((unsigned)qy);
+    idx[i] = i;
 }
 
 // ---- findCorrespondenceIndexKD (kernel.cu:924-972) over an arbitrary xyz batch --------------
@@ -288,6 +324,10 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
     CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
+    CHK(dalloc(&h->mkey, n)); CHK(dalloc(&h->mkey2, n)); CHK(dalloc(&h->order, n)); CHK(dalloc(&h->order2, n));
+    if (pfslam_sort_pairs_u32(nullptr, &h->sort_tmp_bytes, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, nullptr))
+        return fail("pfslam_create: radix sort workspace query failed");
+    HIPCHK(hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
     CHK(dalloc(&h->stats, 8)); CHK(dalloc(&h->pose, 4)); CHK(dalloc(&h->start, 4));
     CHK(dalloc(&h->icp_tar, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_cor, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_dbg, 32));
     CHK(dalloc(&h->free_mask, M)); CHK(dalloc(&h->wall_mask, M));
@@ -330,7 +370,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw,
-                    h->fit, h->fit_i, h->partial, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
+                    h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->wall_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->new_pts, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
                     h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_hdr};
@@ -557,17 +597,27 @@ static int launch_score(pfslam_handle *h)
         }
         out = h->partial;
     }
+    const int *order = nullptr;
+    if (h->variant != 1 && h->n > 64) { // variant 1 = identity order (A/B of the Morton ordering)
+        hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose,
+                           h->mkey, h->order);
+        size_t tb = h->sort_tmp_bytes;
+        if (pfslam_sort_pairs_u32(h->sort_tmp, &tb, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, h->stream))
+            return fail("particle Morton sort failed");
+        order = h->order2;
+    }
     dim3 grid((h->n + 255) / 256, used);
+    const int direct = used > 1 ? 0 : 1;
     if (h->planar)
         hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
-                           bpc, kd_view(h), out);
+                           bpc, kd_view(h), order, direct, out);
     else
         hipLaunchKernelGGL(k_score_kd<false>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
-                           bpc, kd_view(h), out);
+                           bpc, kd_view(h), order, direct, out);
     HIPCHK(hipGetLastError());
     if (used > 1) {
         hipLaunchKernelGGL(k_reduce_partials, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n,
-                           used, h->fit);
+                           used, order, h->fit);
         HIPCHK(hipGetLastError());
     }
     return 0;

@@ -23,7 +23,7 @@ SYMBOLS = [
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
-    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers",
+    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size",
 ]
 
 
@@ -83,6 +83,10 @@ def load():
     L.pfslam_icp.argtypes = [vp, vp, vp, vp]
     L.pfslam_update_map_kd.argtypes = [vp]
     L.pfslam_resample.argtypes = [vp, i32, vp, vp]
+    L.pfslam_resample_plan.argtypes = [vp, i32, vp, vp]
+    L.pfslam_resample_gather.argtypes = [vp]
+    L.pfslam_maybe_balance.argtypes = [vp, i32]
+    L.pfslam_kd_size.argtypes = [vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -229,11 +233,15 @@ class PfSlam:
              "pfslam_measurement_apply")
         return best.value, fmin.value, fmax.value
 
-    def icp(self, start):
-        start = np.ascontiguousarray(start, dtype=np.float32)
+    def icp(self, start=None):
+        """start=None: use the device-resident best-particle pose left by measurement_apply."""
         out = np.zeros(3, np.float32)
         dbg = np.zeros(32, np.float32)
-        _chk(self.L.pfslam_icp(self._h, _p(start), _p(out), _p(dbg)), "pfslam_icp")
+        if start is None:
+            _chk(self.L.pfslam_icp(self._h, None, _p(out), _p(dbg)), "pfslam_icp")
+        else:
+            start = np.ascontiguousarray(start, dtype=np.float32)
+            _chk(self.L.pfslam_icp(self._h, _p(start), _p(out), _p(dbg)), "pfslam_icp")
         return out, dbg
 
     def update_map_kd(self):
@@ -243,6 +251,21 @@ class PfSlam:
         did, neff = C.c_int(), C.c_float()
         _chk(self.L.pfslam_resample(self._h, frame, C.byref(did), C.byref(neff)), "pfslam_resample")
         return did.value, neff.value
+
+    def maybe_balance(self, frame):
+        _chk(self.L.pfslam_maybe_balance(self._h, frame), "pfslam_maybe_balance")
+
+    @property
+    def kd_size(self):
+        return self.L.pfslam_kd_size(self._h)
+
+    def resample_plan(self, frame):
+        did, neff = C.c_int(), C.c_float()
+        _chk(self.L.pfslam_resample_plan(self._h, frame, C.byref(did), C.byref(neff)), "pfslam_resample_plan")
+        return did.value, neff.value
+
+    def resample_gather(self):
+        _chk(self.L.pfslam_resample_gather(self._h), "pfslam_resample_gather")
 
     def score_grid(self):
         fit = np.empty(self.n, np.int32)

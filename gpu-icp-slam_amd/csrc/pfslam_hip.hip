@@ -73,6 +73,9 @@ struct pfslam_handle {
     // particles, SoA; pos double-buffered for the resample gather
     float *x = nullptr, *y = nullptr, *th = nullptr, *w = nullptr, *wm = nullptr;
     float *x2 = nullptr, *y2 = nullptr, *th2 = nullptr;
+    // global views for the resample (all ranks' particles); alias the local arrays when not sharded
+    float *gw = nullptr, *gx = nullptr, *gy = nullptr, *gth = nullptr;
+    bool own_global = false;
     float *scan = nullptr;
     // map
     int kd_size = 0, kd_cap = 0, planar = 1;
@@ -320,6 +323,11 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     const size_t n = h->n, M = (size_t)h->dimx * h->dimy;
     CHK(dalloc(&h->x, n)); CHK(dalloc(&h->y, n)); CHK(dalloc(&h->th, n)); CHK(dalloc(&h->w, n)); CHK(dalloc(&h->wm, n));
     CHK(dalloc(&h->x2, n)); CHK(dalloc(&h->y2, n)); CHK(dalloc(&h->th2, n));
+    if (h->gn != h->n) {
+        if (h->goff < 0 || h->goff + h->n > h->gn) return fail("pfslam_create: shard [global_offset, +n_particles) exceeds global_n");
+        CHK(dalloc(&h->gw, (size_t)h->gn)); CHK(dalloc(&h->gx, (size_t)h->gn)); CHK(dalloc(&h->gy, (size_t)h->gn)); CHK(dalloc(&h->gth, (size_t)h->gn));
+        h->own_global = true;
+    }
     CHK(dalloc(&h->scan, (size_t)h->nb));
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
@@ -338,9 +346,10 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     CHK(dalloc(&h->wall_pts, (size_t)h->max_wall)); CHK(dalloc(&h->free_pts, (size_t)h->max_free));
     CHK(dalloc(&h->wall_c, (size_t)h->max_wall)); CHK(dalloc(&h->free_c, (size_t)h->max_free));
     CHK(dalloc(&h->new_pts, (size_t)h->max_wall)); CHK(dalloc(&h->counts, 8));
-    const size_t nt_sum = (n + PF_SUM_TILE - 1) / PF_SUM_TILE, nt_scan = (n + PF_SCAN_TILE - 1) / PF_SCAN_TILE;
+    const size_t G = (size_t)h->gn;
+    const size_t nt_sum = (G + PF_SUM_TILE - 1) / PF_SUM_TILE, nt_scan = (G + PF_SCAN_TILE - 1) / PF_SCAN_TILE;
     CHK(dalloc(&h->tile_r, nt_sum)); CHK(dalloc(&h->tile_r2, nt_sum)); CHK(dalloc(&h->sums, 4));
-    CHK(dalloc(&h->cdf, n)); CHK(dalloc(&h->chunk_max, (n + PF_SCAN_CHUNK - 1) / PF_SCAN_CHUNK));
+    CHK(dalloc(&h->cdf, G)); CHK(dalloc(&h->chunk_max, (G + PF_SCAN_CHUNK - 1) / PF_SCAN_CHUNK));
     CHK(dalloc(&h->tile_tot, nt_scan)); CHK(dalloc(&h->tile_off, nt_scan)); CHK(dalloc(&h->tile_pmax, nt_scan));
     CHK(dalloc(&h->src, n));
     CHK(dalloc(&h->grid, M));
@@ -376,6 +385,9 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
                     h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_hdr};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (h->own_global) {
+        (void)hipFree(h->gw); (void)hipFree(h->gx); (void)hipFree(h->gy); (void)hipFree(h->gth);
+    }
     if (h->h_hdr) (void)hipHostFree(h->h_hdr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -710,6 +722,10 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
     case 7: *ptr = h->scan; *bytes = (size_t)h->nb * 4; break;
     case 8: *ptr = h->start; *bytes = 16; break;
     case 9: *ptr = h->pose; *bytes = 16; break;
+    case 10: *ptr = h->own_global ? h->gw : h->w; *bytes = (size_t)h->gn * 4; break;
+    case 11: *ptr = h->own_global ? h->gx : h->x; *bytes = (size_t)h->gn * 4; break;
+    case 12: *ptr = h->own_global ? h->gy : h->y; *bytes = (size_t)h->gn * 4; break;
+    case 13: *ptr = h->own_global ? h->gth : h->th; *bytes = (size_t)h->gn * 4; break;
     default: return fail("pfslam_device_ptr: unknown buffer");
     }
     return 0;

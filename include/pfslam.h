@@ -109,12 +109,22 @@ int pfslam_measurement_update(pfslam_handle *h, int *best, float *fmin, float *f
 int pfslam_icp(pfslam_handle *h, const float start[3], float pose_out[3], float *dbg29);
 int pfslam_update_map_kd(pfslam_handle *h);
 int pfslam_resample(pfslam_handle *h, int frame, int *resampled, float *neff);
+/* the two halves of pfslam_resample, for sharded handles: plan = Neff + cdf + source indices on the GLOBAL weights
+ * (device buffer 10, filled by the caller's all-gather); gather = pull the chosen particles out of the GLOBAL pose
+ * arrays (device buffers 11-13, all-gathered by the caller when plan reports resampled = 1) */
+int pfslam_resample_plan(pfslam_handle *h, int frame, int *resampled, float *neff);
+int pfslam_resample_gather(pfslam_handle *h);
 int pfslam_score_grid(pfslam_handle *h, int32_t *fit_host);
 int pfslam_update_map_grid(pfslam_handle *h);
 
 /* batch KD "nearest neighbour" with the reference traversal (findCorrespondenceIndexKD, kernel.cu:924-972);
  * xyz_host: n*3 floats; best_host: n ints */
 int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *best_host);
+
+/* the frame % balance_period == 5 re-balance that pfslam_step performs first (kernel.cu:1707-1711), as its own
+ * entry for callers that drive the stages themselves; pfslam_kd_size = number of map nodes (kdSize) */
+int pfslam_maybe_balance(pfslam_handle *h, int frame);
+int pfslam_kd_size(pfslam_handle *h);
 
 /* ---- multi-GPU merge hooks (particles sharded over ranks; collectives are the caller's, e.g. RCCL) ----
  * stats layout (device, 8 x int64): [0] max key, [1] negated-min key (both to be all-reduced with MAX),
@@ -123,7 +133,8 @@ int pfslam_measurement_local(pfslam_handle *h);  /* score must have run; fills t
 int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, float *fmax); /* after the all-reduce */
 /* device pointers of the handle's buffers, for zero-copy wrapping by the harness.
  * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta, 5 w (n x f32 each), 6 weight tile sums,
- *        7 scan (n_beams x f32) */
+ *        7 scan (n_beams x f32), 8 best-particle pose (4 x f32), 9 robot pose (4 x f32),
+ *        10 global w, 11 global x, 12 global y, 13 global theta (global_n x f32 each; alias 5,2,3,4 when unsharded) */
 int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
 
 /* ---- bench support: time `iters` back-to-back launches of the score kernel with HIP events on the

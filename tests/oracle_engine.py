@@ -1,0 +1,167 @@
+"""An engine with the PfSlam stage interface backed by the CPU oracle (TEST INFRASTRUCTURE).  It lets the
+multi-GPU orchestration (gpu-icp-slam_amd/sharded.py) run under gloo on CPU: same partitioning, same packed
+keys, same collectives -- only the per-rank compute is the oracle's instead of the HIP kernels'."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle_lib as O
+
+
+def f32_to_ordered(f):
+    s = np.ascontiguousarray(f, np.float32).view(np.int32).astype(np.int64)
+    return (s ^ ((s >> 31) & 0x7fffffff)).astype(np.int64)
+
+
+def ordered_to_f32(s):
+    s = np.int64(s)
+    v = np.int32(s ^ ((s >> 31) & 0x7fffffff))
+    return np.array([v], np.int32).view(np.float32)[0]
+
+
+def oracle_map_update(tree, size, robot, scan, cap, bug=0):
+    """PFUpdateMapKD (kernel.cu:1406-1540) on a numpy tree buffer; returns the new size."""
+    L = O.lib()
+    dim = 1600
+    fm, wm = O.get_walls(scan, 800, 800, robot[2])
+    patch = O.default_patch()
+    wall = np.zeros((2048, 4), np.float32)
+    free = np.zeros((int(fm.sum()) + 1, 4), np.float32)
+    nw, nf = C.c_int(), C.c_int()
+    rb = np.ascontiguousarray(robot, np.float32)
+    L.orc_masks_to_points(O.P(fm), O.P(wm), dim, dim, C.byref(patch), O.P(rb), O.P(wall), C.byref(nw), O.P(free), C.byref(nf))
+    nw, nf = nw.value, nf.value
+    if size == 0:
+        if nw:
+            L.orc_kd_create(O.P(wall), nw, O.P(tree))
+        return nw
+    if bug:
+        free[nw:nf] = 0
+    fc, _ = O.traverse_batch(tree, free[:nf, :3])
+    wc, _ = O.traverse_batch(tree, wall[:nw, :3])
+    L.orc_update_map_kd(O.P(tree), O.P(free), O.P(fc), nf, -1, C.byref(patch))
+    L.orc_update_map_kd(O.P(tree), O.P(wall), O.P(wc), nw, 4, C.byref(patch))
+    create = np.zeros(max(nw, 1), np.uint8)
+    L.orc_test_correspondence(O.P(tree), O.P(wall), O.P(wc), nw, O.P(create), C.byref(patch))
+    for i in range(nw):
+        if create[i] and size < cap:
+            O.kd_insert(tree, size, np.array([wall[i, 0], wall[i, 1], wall[i, 2], -100], np.float32))
+            size += 1
+    return size
+
+
+class OracleBuffers:
+    def __init__(self, eng):
+        self.eng = eng
+        self.stats = torch.from_numpy(eng.stats)
+        self.start = torch.from_numpy(eng.start)
+        self.w = torch.from_numpy(eng.w)
+        self.gw = torch.from_numpy(eng.gw)
+
+    def pose_views(self):
+        e = self.eng
+        return ([torch.from_numpy(a) for a in (e.x, e.y, e.th)], [torch.from_numpy(a) for a in (e.gx, e.gy, e.gth)])
+
+
+class OracleShardEngine:
+    def __init__(self, n_local, goff, gn, kd_capacity=1 << 16, strict_host_mirror=1, balance_period=100):
+        self.n, self.goff, self.gn, self.cap = n_local, goff, gn, kd_capacity
+        self.strict, self.period = strict_host_mirror, balance_period
+        z = lambda k: np.zeros(k, np.float32)
+        self.x, self.y, self.th, self.w, self.wm = z(n_local), z(n_local), z(n_local), np.ones(n_local, np.float32), np.ones(n_local, np.float32)
+        self.gw, self.gx, self.gy, self.gth = z(gn), z(gn), z(gn), z(gn)
+        self.stats = np.zeros(8, np.int64)
+        self.start = z(4)
+        self.tree = np.zeros(kd_capacity, O.NODE_DTYPE)
+        self.size = 0
+        self.robot = z(3)
+        self.fit = z(n_local)
+        self.scan = None
+        self.src = None
+
+    # ---- helpers
+    def _aos(self):
+        p = O.make_particles(self.n)
+        p["x"], p["y"], p["theta"], p["w"] = self.x, self.y, self.th, self.w
+        return p
+
+    def _from_aos(self, p):
+        self.x[:], self.y[:], self.th[:], self.w[:] = p["x"], p["y"], p["theta"], p["w"]
+
+    # ---- stage interface
+    def set_scan(self, scan): self.scan = np.ascontiguousarray(scan, np.float32)
+    def set_pose(self, pose): self.robot[:] = pose
+    def set_map(self, tree): self.tree[:len(tree)] = tree; self.size = len(tree)
+    def set_stream(self, s): pass
+    def synchronize(self): pass
+    @property
+    def kd_size(self): return self.size
+    @property
+    def pose(self): return self.robot.copy()
+
+    def maybe_balance(self, frame):
+        if self.period > 0 and frame % self.period == 5 and self.size > 0:
+            O.lib().orc_kd_balance(O.P(self.tree), self.size)
+
+    def update_map_kd(self):
+        self.size = oracle_map_update(self.tree, self.size, self.robot, self.scan, self.cap)
+
+    def motion_update(self, frame):
+        self.w[:] = self.wm  # H2D of the host-side particle array (kernel.cu:408)
+        p = self._aos()
+        O.add_noise(p, frame, idx0=self.goff)
+        self._from_aos(p)
+
+    def score_kd(self, fetch=True):
+        self.fit = O.score_kd(self.tree, self._aos(), self.scan)
+        return self.fit if fetch else None
+
+    def measurement_local(self):
+        gi = (self.goff + np.arange(self.n)).astype(np.int64)
+        self.stats[:] = 0
+        self.stats[0] = np.max((f32_to_ordered(self.fit) << 32) | (0xFFFFFFFF - gi))
+        self.stats[1] = np.max(f32_to_ordered(-self.fit) << 32)
+
+    def measurement_apply(self):
+        fmax = ordered_to_f32(self.stats[0] >> 32)
+        fmin = -ordered_to_f32(self.stats[1] >> 32)
+        best = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF))
+        rng = np.float32(fmax) - np.float32(fmin)
+        if rng > 0:
+            p = self._aos()
+            O.lib().orc_update_weights_f32(O.P(p), self.n, O.P(self.fit), float(np.float32(1) / rng), int(fmin))
+            self._from_aos(p)
+        mirror = (self.gn + 1) // 2 if self.strict else 1 << 62
+        sel = (self.goff + np.arange(self.n)) < mirror
+        self.wm[sel] = self.w[sel]
+        lb = best - self.goff
+        self.start[:] = 0
+        if 0 <= lb < self.n:
+            self.start[:3] = (self.x[lb], self.y[lb], self.th[lb])
+        return best, float(fmin), float(fmax)
+
+    def icp(self, start=None):
+        s = self.start[:3] if start is None else np.asarray(start, np.float32)
+        pose, dbg = O.icp(self.tree, self.robot, s, self.scan)
+        self.robot[:] = pose
+        return pose, dbg
+
+    def resample_plan(self, frame):
+        L = O.lib()
+        w2 = (self.gw * self.gw).astype(np.float32)
+        r = np.float32(L.orc_sum_f32(O.P(self.gw), self.gn, 1))
+        r2 = np.float32(L.orc_sum_f32(O.P(w2), self.gn, 1))
+        neff = np.float32(r * r) / r2
+        did = float(neff) < 0.7 * self.gn
+        if did:
+            cdf = np.zeros(self.gn, np.float32)
+            L.orc_inclusive_scan_f32(O.P(self.gw), self.gn, O.P(cdf))
+            self.src = np.zeros(self.n, np.int32)
+            L.orc_weighted_sample_indices(O.P(cdf), self.gn, float(neff), frame, self.goff, self.n, O.P(self.src))
+        return int(did), float(neff)
+
+    def resample_gather(self):
+        self.x[:], self.y[:], self.th[:] = self.gx[self.src], self.gy[self.src], self.gth[self.src]
+        self.w[:] = 1
+        self.wm[:] = 1

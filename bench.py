@@ -80,7 +80,8 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ)  # torchrun, even with 1 rank
+    if distributed:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -98,7 +99,7 @@ def main():
         pose = (0.002 * f, 0.001 * f, 0.0004 * f)
         scans.append(pkg.synth.make_scan(segs, pose, seed=2000 + f))
 
-    if world > 1:
+    if distributed:
         from importlib import import_module
         sharded = import_module("gpu-icp-slam_amd.sharded")
         eng = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=a.map_points + (1 << 17), dist=dist, torch=torch)
@@ -157,7 +158,7 @@ def main():
                 out["cpu_baseline"] = cb
             bytes_per_eval = bvalid * vbar * 32.0 + 20.0  # B_valid x V x 32 B + 16 B in + 4 B out
             launches = max(timers["score_launches"], 1)
-            kern_ms = timers["score_ms"] / launches
+            kern_ms = max(timers["score_ms"] / launches, 1e-9)
             achieved = bytes_per_eval * n_local / (kern_ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_score_kd.json")

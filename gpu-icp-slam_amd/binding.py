@@ -44,6 +44,28 @@ class PfSlamError(RuntimeError):
 _lib = None
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  If this library initialises /opt/rocm's copy first,
+    a later `import torch` in the same process sees "No HIP GPUs" (two runtimes).  When torch is installed but not
+    yet imported, pre-load ITS runtime globally so that both bind to one copy.  No torch -> nothing to do."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PFSLAM_NO_TORCH_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Build (if stale) and load libpfslam_hip.so.  Raises if that is not possible."""
     global _lib
@@ -56,6 +78,7 @@ def load():
         except Exception as e:  # a prebuilt .so that travelled with the snapshot is still usable
             if not os.path.exists(path):
                 raise PfSlamError("libpfslam_hip.so is missing and could not be built: %s" % e)
+    _one_hip_runtime()
     L = C.CDLL(path)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     L.pfslam_last_error.restype = C.c_char_p

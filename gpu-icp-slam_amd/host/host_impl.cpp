@@ -1,0 +1,198 @@
+// host_impl.cpp -- C++ host layer above the C-ABI: the reference's kernel.h / Lidar / Scene / Pointcloud /
+// KDTree surface.  Module-global state and print-and-exit errors mirror the reference (kernel.cu:55-83,
+// kernel.h:42-60); everything else is a thin forwarding layer onto include/pfslam.h.
+#include "kernel.h"
+#include "pointcloud.h"
+#include "../../include/pfslam.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+
+// ---------------------------------------------------------------- KDTree
+static_assert(sizeof(KDTree::Node) == sizeof(pfslam_node), "Node layout");
+void KDTree::Create(std::vector<glm::vec4> input, Node *list)
+{
+    pfslam_kd_create(reinterpret_cast<const float *>(input.data()), (int)input.size(), reinterpret_cast<pfslam_node *>(list));
+}
+void KDTree::InsertNode(glm::vec4 point, Node *list, int listSize)
+{
+    const float p[4] = {point.x, point.y, point.z, point.w};
+    pfslam_kd_insert_node(p, reinterpret_cast<pfslam_node *>(list), listSize);
+}
+void KDTree::Balance(Node *list, int listSize) { pfslam_kd_balance(reinterpret_cast<pfslam_node *>(list), listSize); }
+
+// ---------------------------------------------------------------- loaders
+static std::vector<std::string> tokens_of(const std::string &line)
+{
+    std::istringstream ss(line);
+    std::vector<std::string> out;
+    std::string t;
+    while (ss >> t) out.push_back(t);
+    return out;
+}
+static bool next_line(std::ifstream &f, std::string &line)
+{
+    if (!std::getline(f, line)) { line.clear(); return false; }
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    return true;
+}
+
+Lidar::Lidar(std::string filename)
+{
+    std::cout << "Reading lidar data from " << filename << " ..." << std::endl;
+    std::ifstream f(filename, std::ios::binary);
+    if (!f.is_open()) {
+        std::cout << "Error reading from file - aborting!" << std::endl;
+        throw std::runtime_error("Lidar: cannot open " + filename);
+    }
+    f.seekg(0, std::ios::end);
+    const std::streamoff bytes = f.tellg();
+    f.seekg(0);
+    const int beams = 1081;
+    if (bytes % (beams * 4) != 0) throw std::runtime_error("Lidar: file is not frames x 1081 float32 (convert .mat with tools/mat2bin.py)");
+    const size_t frames = (size_t)(bytes / (beams * 4));
+    scans.resize(frames, std::vector<float>(beams));
+    for (size_t i = 0; i < frames; i++) f.read(reinterpret_cast<char *>(scans[i].data()), beams * 4);
+}
+
+Scene::Scene(std::string filename)
+{
+    std::cout << "Reading scene from " << filename << " ..." << std::endl;
+    fp_in.open(filename);
+    if (!fp_in.is_open()) {
+        std::cout << "Error reading from file - aborting!" << std::endl;
+        throw std::runtime_error("Scene: cannot open " + filename);
+    }
+    std::string line;
+    while (next_line(fp_in, line)) {
+        const auto t = tokens_of(line);
+        if (t.empty()) continue;
+        if (t[0] == "MAP") loadGeom();
+        else if (t[0] == "CAMERA") loadCamera();
+    }
+}
+int Scene::loadGeom()
+{
+    glm::vec3 gridSize;
+    float res = 1.0f;
+    std::string line;
+    while (next_line(fp_in, line) && !line.empty()) {
+        const auto t = tokens_of(line);
+        if (t.empty()) break;
+        if (t[0] == "SIZE" && t.size() >= 3) gridSize = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), 0);
+        else if (t[0] == "RES" && t.size() >= 2) res = (float)atof(t[1].c_str());
+    }
+    Patch m;
+    m.scale = gridSize;
+    m.resolution = glm::vec3(res, res, 1.0f);
+    m.grid = nullptr;
+    m.uid = 0;
+    maps.push_back(m);
+    return 1;
+}
+int Scene::loadCamera()
+{
+    Camera &c = state.camera;
+    std::string line;
+    while (next_line(fp_in, line) && !line.empty()) {
+        const auto t = tokens_of(line);
+        if (t.empty()) break;
+        if (t[0] == "RES" && t.size() >= 3) c.resolution = glm::ivec2(atoi(t[1].c_str()), atoi(t[2].c_str()));
+        else if (t[0] == "FOVY" && t.size() >= 2) c.fov.y = (float)atof(t[1].c_str());
+        else if (t[0] == "FILE" && t.size() >= 2) state.imageName = t[1];
+        else if (t[0] == "EYE" && t.size() >= 4) c.position = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
+        else if (t[0] == "LOOKAT" && t.size() >= 4) c.lookAt = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
+        else if (t[0] == "UP" && t.size() >= 4) c.up = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
+    }
+    return 1;
+}
+
+Pointcloud::Pointcloud(std::string filename)
+{
+    std::ifstream f(filename);
+    if (!f.is_open()) throw std::runtime_error("Pointcloud: cannot open " + filename);
+    std::string line;
+    int i = 0;
+    while (next_line(f, line)) {
+        const auto t = tokens_of(line);
+        if (t.size() < 3) continue;
+        points.push_back(glm::vec4((float)atoi(t[2].c_str()), (float)atoi(t[0].c_str()), (float)atoi(t[1].c_str()), (float)i++));
+    }
+}
+
+// ---------------------------------------------------------------- kernel.h
+static pfslam_handle *g_handle = nullptr;
+static Scene *g_scene = nullptr;
+static int g_particles = 1000; // PARTICLE_COUNT, kernel.cu:30
+static glm::vec3 g_robotPos;
+
+void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line)
+{
+    if (rc == 0) return;
+    fprintf(stderr, "pfslam error (%s:%d): %s: %s\n", file, line, msg, pfslam_last_error());
+    exit(EXIT_FAILURE);
+}
+#define PFCHK(call, msg) checkPfslamErrorFn((call), msg, __FILE__, __LINE__)
+
+void pfslamSetParticleCount(int n) { if (n > 0) g_particles = n; }
+
+void particleFilterInit(Scene *scene)
+{
+    g_scene = scene;
+    if (const char *e = getenv("PFSLAM_PARTICLES")) pfslamSetParticleCount(atoi(e));
+    pfslam_config cfg;
+    pfslam_default_config(&cfg);
+    cfg.n_particles = g_particles;
+    if (scene && !scene->maps.empty()) { // map_params = scene->maps[0] (kernel.cu:119)
+        cfg.map_scale_x = scene->maps[0].scale.x;
+        cfg.map_scale_y = scene->maps[0].scale.y;
+        cfg.map_res_x = scene->maps[0].resolution.x;
+        cfg.map_res_y = scene->maps[0].resolution.y;
+    }
+    if (const char *e = getenv("PFSLAM_KD_CAPACITY")) cfg.kd_capacity = atoi(e);
+    PFCHK(pfslam_create(&cfg, &g_handle), "particleFilterInit");
+    g_robotPos = glm::vec3(0.0f);
+    particleFilterInitPC();
+}
+void particleFilterFree()
+{
+    if (g_handle) PFCHK(pfslam_destroy(g_handle), "particleFilterFree");
+    g_handle = nullptr;
+    particleFilterFreePC();
+}
+void particleFilterInitPC() {} // folded into pfslam_create
+void particleFilterFreePC() {}
+
+void particleFilter(uchar4 *, int frame, Lidar *lidar)
+{
+    if (!g_handle || !lidar || frame < 0 || (size_t)frame >= lidar->scans.size()) {
+        fprintf(stderr, "particleFilter: not initialised or frame out of range\n");
+        exit(EXIT_FAILURE);
+    }
+    PFCHK(pfslam_step(g_handle, frame, lidar->scans[frame].data()), "particleFilter");
+}
+void drawMap(uchar4 *) {}
+
+void getPCData(Particle **ptrParticles, MAP_TYPE **ptrMap, KDTree::Node **ptrKD, int *nParticles, int *nKD, glm::vec3 &pos)
+{
+    const pfslam_particle *p = nullptr;
+    const pfslam_node *kd = nullptr;
+    const int8_t *grid = nullptr;
+    int np = 0, nk = 0, dx = 0, dy = 0;
+    PFCHK(pfslam_get_particles(g_handle, &p, &np), "getPCData particles");
+    PFCHK(pfslam_get_map(g_handle, &kd, &nk), "getPCData map");
+    PFCHK(pfslam_get_grid(g_handle, &grid, &dx, &dy), "getPCData grid");
+    float pose[3];
+    PFCHK(pfslam_get_pose(g_handle, pose), "getPCData pose");
+    // non-owning pointers into the library's host mirrors, valid until the next particleFilter / Free (kernel.cu:803-813)
+    *ptrParticles = reinterpret_cast<Particle *>(const_cast<pfslam_particle *>(p));
+    *ptrMap = reinterpret_cast<MAP_TYPE *>(const_cast<int8_t *>(grid));
+    *ptrKD = reinterpret_cast<KDTree::Node *>(const_cast<pfslam_node *>(kd));
+    *nParticles = np;
+    *nKD = nk;
+    pos = glm::vec3(pose[0], pose[1], pose[2]);
+}

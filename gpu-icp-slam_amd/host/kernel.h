@@ -1,0 +1,28 @@
+// kernel.h -- drop-in for the reference's src/kernel.h:14-24: same free functions, same structs, implemented on
+// libpfslam_hip.so (MI355X).  pbo arguments are accepted and ignored exactly as particleFilter() ignores its own
+// (kernel.cu:1702, H9); drawMap is a no-op (visualisation is out of scope).
+#pragma once
+#include <vector>
+#include "kdtree.hpp"
+#include "lidar.h"
+#include "scene.h"
+
+#ifndef __HIP_PLATFORM_AMD__
+struct uchar4 { unsigned char x, y, z, w; };
+#endif
+
+void particleFilterInit(Scene *scene);
+void particleFilterFree();
+void particleFilter(uchar4 *pbo, int frame, Lidar *lidar);
+void drawMap(uchar4 *pbo);
+void getPCData(Particle **ptrParticles, MAP_TYPE **ptrMap, KDTree::Node **ptrKD, int *nParticles, int *nKD, glm::vec3 &pos);
+void particleFilterInitPC();
+void particleFilterFreePC();
+
+// PARTICLE_COUNT is a compile-time 1000 in the reference (kernel.cu:30); here it is a runtime setting read by the
+// next particleFilterInit (also: environment variable PFSLAM_PARTICLES).
+void pfslamSetParticleCount(int n);
+
+// error convention of the reference: print and exit (kernel.h:42-60)
+void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line);
+#define checkCUDAError(msg) checkPfslamErrorFn(0, msg, __FILE__, __LINE__)

@@ -1,0 +1,38 @@
+// selftest.cpp -- no-GPU check of the C++ host layer: loaders and the KDTree facade.
+//   pfslam_host_selftest <scene.txt> <lidar.f32> <cloud.txt>
+#include <cstdio>
+#include <cstring>
+#include "kernel.h"
+#include "pointcloud.h"
+#include "../../include/pfslam.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    Scene scene(argv[1]);
+    if (scene.maps.size() != 1) return 10;
+    printf("map %.6f %.6f %.6f cam %d %d eye %.3f %.3f %.3f file %s\n", scene.maps[0].scale.x, scene.maps[0].scale.y,
+           scene.maps[0].resolution.x, scene.state.camera.resolution.x, scene.state.camera.resolution.y,
+           scene.state.camera.position.x, scene.state.camera.position.y, scene.state.camera.position.z,
+           scene.state.imageName.c_str());
+    Lidar lidar(argv[2]);
+    printf("lidar %zu %zu %.6f %.6f\n", lidar.scans.size(), lidar.scans[0].size(), lidar.scans[0][0], lidar.scans.back().back());
+    Pointcloud pc(argv[3]);
+    printf("cloud %zu %.0f %.0f %.0f %.0f\n", pc.points.size(), pc.points[1].x, pc.points[1].y, pc.points[1].z, pc.points[1].w);
+    // KDTree facade == C-ABI
+    std::vector<glm::vec4> pts;
+    for (int i = 0; i < 257; i++) pts.push_back(glm::vec4((float)((i * 37) % 19) * 0.025f, (float)((i * 11) % 23) * 0.025f, 0.0f, (float)(i % 7)));
+    std::vector<KDTree::Node> a(300);
+    std::vector<pfslam_node> b(300);
+    KDTree::Create(pts, a.data());
+    pfslam_kd_create(reinterpret_cast<const float *>(pts.data()), 257, b.data());
+    KDTree::InsertNode(glm::vec4(0.3f, 0.1f, 0.0f, -100.0f), a.data(), 257);
+    const float p[4] = {0.3f, 0.1f, 0.0f, -100.0f};
+    pfslam_kd_insert_node(p, b.data(), 257);
+    if (memcmp(a.data(), b.data(), 258 * 32) != 0) return 11;
+    KDTree::Balance(a.data(), 258);
+    pfslam_kd_balance(b.data(), 258);
+    if (memcmp(a.data(), b.data(), 258 * 32) != 0) return 12;
+    printf("kdtree ok root %d %d %d\n", a[0].axis, a[0].left, a[0].right);
+    return 0;
+}

@@ -1,0 +1,70 @@
+"""The C++ host layer (gpu-icp-slam_amd/host: kernel.h / Lidar / Scene / Pointcloud / KDTree drop-ins)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gpu-icp-slam_amd", "host")
+
+SCENE_TXT = """// Camera
+CAMERA
+RES         800 800
+FOVY        45
+FILE        map0
+EYE         0.0 0.0 25
+LOOKAT      0 0 0
+UP          0 1 0
+
+// Patch size in meters
+MAP
+SIZE \t40 40
+RES\t.025
+"""
+
+
+def build_host(pkg):
+    pkg.load()
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+
+
+def test_loaders_and_kdtree_facade(tmp_path, pkg):
+    build_host(pkg)
+    scene = tmp_path / "scene.txt"
+    scene.write_text(SCENE_TXT)  # same format as the reference's data/map_settings.txt
+    scans = np.arange(3 * 1081, dtype=np.float32).reshape(3, 1081) * 0.01
+    lidar = tmp_path / "lidar.f32"
+    scans.tofile(str(lidar))
+    cloud = tmp_path / "cloud.txt"
+    cloud.write_text("1 2 3\n4 5 6\n7 8 9\n")
+    out = subprocess.check_output([os.path.join(HOST, "pfslam_host_selftest"), str(scene), str(lidar), str(cloud)]).decode()
+    assert "map 40.000000 40.000000 0.025000 cam 800 800 eye 0.000 0.000 25.000 file map0" in out
+    assert "lidar 3 1081 0.000000 %.6f" % scans[-1, -1] in out
+    assert "cloud 3 6 4 5 1" in out       # vec4(third, first, second, line index), pointcloud.cpp:22
+    assert "kdtree ok root 0 1" in out
+
+
+@pytest.mark.gpu
+def test_replay_binary_matches_python_step(tmp_path, pkg):
+    """kernel.h shim (particleFilterInit / particleFilter / getPCData) == the C-ABI driven from Python."""
+    assert pkg.device_count() > 0
+    build_host(pkg)
+    segs, frames = pkg.synth.corridor_sequence(9, seed=5)
+    scene = tmp_path / "scene.txt"
+    scene.write_text(SCENE_TXT)
+    scans = np.stack([np.zeros(1081, np.float32)] + [s for _, s in frames])  # scans[0] is never used (frame starts at 1)
+    lidar = tmp_path / "lidar.f32"
+    scans.astype(np.float32).tofile(str(lidar))
+    env = dict(os.environ, PFSLAM_PARTICLES="300", PFSLAM_KD_CAPACITY=str(1 << 16))
+    out = subprocess.check_output([os.path.join(HOST, "pfslam_replay"), str(scene), str(lidar)], env=env).decode()
+    lines = [l for l in out.splitlines() if l.startswith("frame ")]
+    assert len(lines) == len(frames)
+    h = pkg.PfSlam(300, kd_capacity=1 << 16)
+    for f, ((pose, scan), line) in enumerate(zip(frames, lines), start=1):
+        h.step(f, scan)
+        tok = line.split()
+        got = [int(tok[k], 16) for k in (7, 8, 9)]
+        assert got == h.pose.view(np.uint32).tolist(), line
+        assert int(tok[-1]) == h.trace()["kd_size"] and int(tok[-3]) == 300
+    h.close()

@@ -37,7 +37,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=100000, help="particles per GPU")
     ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
@@ -54,11 +54,15 @@ def cpu_baseline(O, tree, particles, scan, sample):
     fit1, visits, valid = O.score_kd(tree, particles[:one], scan, stats=True)
     t1 = time.perf_counter() - t0
     rate1 = one / t1
-    if sample <= 0:  # ~10-15 s of CPU work across all cores
-        sample = int(min(len(particles), max(one, rate1 * cores * 12)))
-    t0 = time.perf_counter()
-    O.score_kd(tree, particles[:sample], scan, threads=cores)
-    tm = time.perf_counter() - t0
+    if sample <= 0:  # ~10-20 s of CPU core time, at least 64 particles per thread
+        sample = int(min(len(particles), max(one, 64 * cores, rate1 * 15)))
+    best = None
+    for _ in range(3):  # best of 3 (thread start-up noise)
+        t0 = time.perf_counter()
+        O.score_kd(tree, particles[:sample], scan, threads=cores)
+        tm = time.perf_counter() - t0
+        best = tm if best is None else min(best, tm)
+    tm = best
     return {
         "value": sample / tm, "unit": "particle-scan evals/s", "cores": cores, "kind": "port",
         "sample": "%d particles x 1081 beams, 100k-point map, oracle A5 restatement, %d pthreads, -O3 -mavx2 -mfma "
@@ -115,6 +119,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # initial condition: a particle cloud already dispersed around the start pose (5 dispersion steps), so that the
+    # first scoring launches behave like steady state instead of scoring 100 k coincident particles
+    for f in range(1, 6):
+        eng.motion_update(f)
     frame = FIRST_FRAME
     for k in range(a.warmup):
         eng.step(frame, scans[k]); frame += 1
@@ -148,13 +156,17 @@ def main():
         # ---- roofline of the dominant kernel + CPU baseline (N = 1 only) -------------------------
         if world == 1:
             import oracle_lib as O
-            p0 = O.make_particles(n_local)
-            O.add_noise(p0, FIRST_FRAME)
+            # the oracle measures V (mean node visits of the reference traversal) and the CPU rate on the map and the
+            # particle cloud as they are at the END of the timed region (the map grows where the scan lands)
+            e0 = eng.eng if hasattr(eng, "eng") else eng
+            tree_end = np.ascontiguousarray(e0.map(), dtype=O.NODE_DTYPE)
+            p0 = np.ascontiguousarray(e0.particles(), dtype=O.PARTICLE_DTYPE)
+            last_scan = scans[n_frames - 1]
             if a.no_cpu_baseline:
-                _, visits, valid = O.score_kd(tree, p0[:128], scans[0], stats=True)
+                _, visits, valid = O.score_kd(tree_end, p0[:128], last_scan, stats=True)
                 vbar, bvalid = visits / max(valid, 1), valid / 128
             else:
-                cb, vbar, bvalid = cpu_baseline(O, tree, p0, scans[0], a.cpu_sample)
+                cb, vbar, bvalid = cpu_baseline(O, tree_end, p0, last_scan, a.cpu_sample)
                 out["cpu_baseline"] = cb
             bytes_per_eval = bvalid * vbar * 32.0 + 20.0  # B_valid x V x 32 B + 16 B in + 4 B out
             launches = max(timers["score_launches"], 1)

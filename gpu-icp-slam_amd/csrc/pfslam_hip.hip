@@ -124,7 +124,7 @@ struct pfslam_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // live timing of the dominant kernel inside pfslam_step (bench.py roofline leg)
     int timing = 0;
-    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_pending;
     double score_ms = 0.0;
     long score_launches = 0;
 };
@@ -318,8 +318,6 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     h->own_stream = true;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
-    HIPCHK(hipEventCreate(&h->tev0));
-    HIPCHK(hipEventCreate(&h->tev1));
     const size_t n = h->n, M = (size_t)h->dimx * h->dimy;
     CHK(dalloc(&h->x, n)); CHK(dalloc(&h->y, n)); CHK(dalloc(&h->th, n)); CHK(dalloc(&h->w, n)); CHK(dalloc(&h->wm, n));
     CHK(dalloc(&h->x2, n)); CHK(dalloc(&h->y2, n)); CHK(dalloc(&h->th2, n));
@@ -391,8 +389,8 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->h_hdr) (void)hipHostFree(h->h_hdr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->tev0) (void)hipEventDestroy(h->tev0);
-    if (h->tev1) (void)hipEventDestroy(h->tev1);
+    for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -417,9 +415,36 @@ extern "C" int pfslam_synchronize(pfslam_handle *h)
     return 0;
 }
 
+// HIP events bracket exactly the k_score_kd launch (on the stream it is launched on); pairs are collected lazily
+static int flush_timers(pfslam_handle *h)
+{
+    for (auto &e : h->ev_pending) {
+        HIPCHK(hipEventSynchronize(e.second));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        h->score_ms += ms;
+        h->score_launches += 1;
+        h->ev_pool.push_back(e);
+    }
+    h->ev_pending.clear();
+    return 0;
+}
+static int timer_pair(pfslam_handle *h, std::pair<hipEvent_t, hipEvent_t> &p)
+{
+    if (h->ev_pending.size() >= 512) CHK(flush_timers(h));
+    if (h->ev_pool.empty()) {
+        HIPCHK(hipEventCreate(&p.first));
+        HIPCHK(hipEventCreate(&p.second));
+    } else {
+        p = h->ev_pool.back();
+        h->ev_pool.pop_back();
+    }
+    return 0;
+}
 extern "C" int pfslam_set_timing(pfslam_handle *h, int enable)
 {
     if (!h) return fail("null handle");
+    CHK(flush_timers(h));
     h->timing = enable;
     h->score_ms = 0.0;
     h->score_launches = 0;
@@ -428,6 +453,7 @@ extern "C" int pfslam_set_timing(pfslam_handle *h, int enable)
 extern "C" int pfslam_get_timers(pfslam_handle *h, double out[4])
 {
     if (!h || !out) return fail("pfslam_get_timers: bad argument");
+    CHK(flush_timers(h));
     out[0] = h->score_ms;
     out[1] = (double)h->score_launches;
     out[2] = out[3] = 0.0;
@@ -620,6 +646,11 @@ static int launch_score(pfslam_handle *h)
     }
     dim3 grid((h->n + 255) / 256, used);
     const int direct = used > 1 ? 0 : 1;
+    std::pair<hipEvent_t, hipEvent_t> tp{nullptr, nullptr};
+    if (h->timing) {
+        CHK(timer_pair(h, tp));
+        HIPCHK(hipEventRecord(tp.first, h->stream));
+    }
     if (h->planar)
         hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
                            bpc, kd_view(h), order, direct, out);
@@ -627,6 +658,10 @@ static int launch_score(pfslam_handle *h)
         hipLaunchKernelGGL(k_score_kd<false>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
                            bpc, kd_view(h), order, direct, out);
     HIPCHK(hipGetLastError());
+    if (h->timing) {
+        HIPCHK(hipEventRecord(tp.second, h->stream));
+        h->ev_pending.push_back(tp);
+    }
     if (used > 1) {
         hipLaunchKernelGGL(k_reduce_partials, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n,
                            used, order, h->fit);

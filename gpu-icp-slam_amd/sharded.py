@@ -65,15 +65,9 @@ class ShardedSlam:
     # -- pass-throughs
     def set_map(self, tree): self.eng.set_map(tree)
     def set_variant(self, v): self.eng.set_variant(v)
-    def set_timing(self, e):
-        self._timing, self._events = bool(e), []
-
-    def timers(self):
-        """HIP-event time of the scan-match launches (events on the stream the kernels run on: torch's current one)."""
-        if not getattr(self, "_events", None):
-            return {"score_ms": 0.0, "score_launches": 0}
-        self.torch.cuda.synchronize()
-        return {"score_ms": float(sum(a.elapsed_time(b) for a, b in self._events)), "score_launches": len(self._events)}
+    def set_timing(self, e): self.eng.set_timing(e)
+    def timers(self): return self.eng.timers()
+    def motion_update(self, frame): self.eng.motion_update(frame)
     def synchronize(self): self.eng.synchronize()
     def trace(self): return dict(self._last)
     @property
@@ -95,14 +89,7 @@ class ShardedSlam:
             self._last = {"best": -1, "resampled": 0, "kd_size": e.kd_size}
             return
         e.motion_update(frame)
-        if getattr(self, "_timing", False) and self.torch is not None and self.torch.cuda.is_available():
-            ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-            e.score_kd(fetch=False)
-            ev[1].record()
-            self._events.append(ev)
-        else:
-            e.score_kd(fetch=False)
+        e.score_kd(fetch=False)
         e.measurement_local()
         if self.world > 1:
             d.all_reduce(b.stats[:2], op=d.ReduceOp.MAX)

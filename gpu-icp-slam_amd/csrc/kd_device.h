@@ -21,6 +21,16 @@ struct KdView {
     const float *w;     // occupancy weight (Node.value.w)
 };
 
+// Top of the tree staged in LDS (planar maps): the first `levels` levels in BFS order (slot 0 = root,
+// children of slot s = 2s+1, 2s+2), which a median-split tree always fills completely and whose split
+// axis is level % 3.  pos/orig live in LDS, exit[] (global) maps the BFS slots of level `levels` to node indices.
+struct KdTop {
+    const float2 *pos; // LDS: node (x, y) per BFS slot
+    const int *orig;   // LDS: node index per BFS slot
+    const int *exit;   // global: node index (or -1) of the 2^levels children below the staged part
+    int levels;
+};
+
 __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, int left, int right)
 {
     uint4 r;
@@ -48,12 +58,39 @@ __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, i
 // PLANAR: every node has z == 0 and the query has z == 0 (the SLAM map is 2-D): the z term is an
 // exact +0, z-axis levels always branch right and have hyperplane distance 0.
 // H1: the reference reads tree[-1] when the best node is the root; here the search stops.
-template <bool PLANAR>
-__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz)
+#define PF_GUARD_K 0.999999523162841796875f /* 1 - 2^-21 */
+
+template <bool PLANAR, bool USE_TOP = false>
+__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, const KdTop top = KdTop{})
 {
     // bestDist starts as the distance to the root; visiting the root first reproduces that state
     float sBest = INFINITY, sGuard = INFINITY;
     int bestIdx = 0, prevBest = -1, head = 0;
+    if (USE_TOP) {
+        // Phase 1: the staged levels.  Every lane is at the same level, so the split axis is wave-uniform, there is
+        // no loop divergence, and a step costs one ds_read_b64 instead of a 16-byte gather through the L1.
+        int slot = 0, bestSlot = 0;
+        for (int lvl = 0; lvl < top.levels; lvl++) {
+            const float2 nd = top.pos[slot];
+            const float dx = nd.x - px, dy = nd.y - py;
+            const float s = dx * dx + dy * dy;
+            bool take = s < sGuard;
+            const bool inBand = (s < sBest) & !take;
+            if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
+                float sb = sBest;
+                asm volatile("" : "+v"(sb));
+                take = take | (inBand && fsqrt(s) < fsqrt(sb));
+            }
+            sBest = take ? s : sBest;
+            sGuard = take ? s * PF_GUARD_K : sGuard;
+            bestSlot = take ? slot : bestSlot;
+            const int axis = lvl % 3; // scalar
+            const bool lt = axis == 0 ? (px < nd.x) : axis == 1 ? (py < nd.y) : false;
+            slot = 2 * slot + (lt ? 1 : 2);
+        }
+        bestIdx = top.orig[bestSlot];
+        head = top.exit[slot - ((1 << top.levels) - 1)];
+    }
     for (;;) {
         while (head >= 0) { // greedy descent
             const uint4 nd = t.hot[head];
@@ -69,6 +106,8 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             // d < bestDist, decided without a sqrt: if s is below sBest by more than a guard band of 2^-21
             // (relative), the correctly rounded roots differ for certain (sqrt_rn has relative error <= 2^-24 and
             // halves relative gaps); only inside the band -- ~1e-6 of visits -- are the two roots compared.
+            // (The relative bound needs normal floats: it assumes two DISTINCT map points are never both within
+            // 1e-15 m of a query, i.e. squared distances below 1e-30 occur only for exact coincidence, s == 0.)
             bool take = s < sGuard;
             const bool inBand = (s < sBest) & !take;
             if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) { // wave-uniform, almost never taken
@@ -77,7 +116,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
                 take = take | (inBand && fsqrt(s) < fsqrt(sb));
             }
             sBest = take ? s : sBest;
-            sGuard = take ? (s > 1e-30f ? s * 0.999999523162841796875f : 0.0f) : sGuard;
+            sGuard = take ? s * PF_GUARD_K : sGuard;
             bestIdx = take ? head : bestIdx;
             const uint32_t axis = nd.z >> 30;
             float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;

@@ -29,6 +29,8 @@
 #define PF_SUM_TILE 4096
 #define PF_SCAN_TILE 1024
 #define PF_SCAN_CHUNK 16
+#define PF_TOP_LEVELS 12 /* tree levels staged in LDS by the score kernel variant 3 */
+#define PF_TOP_SLOTS ((1 << PF_TOP_LEVELS) - 1)
 
 extern "C" int pfslam_sort_pairs_u32(void *tmp, size_t *tmp_bytes, const unsigned *keys_in, unsigned *keys_out,
                                      const int *vals_in, int *vals_out, int n, int end_bit, void *stream);
@@ -83,6 +85,11 @@ struct pfslam_handle {
     int *parent = nullptr;
     float *kz = nullptr, *kw = nullptr;
     std::vector<pfslam_node> h_nodes; // host mirror (topology + positions; w refreshed on demand)
+    // LDS-staged top of the tree (BFS order)
+    float2 *top_pos = nullptr;
+    int *top_orig = nullptr, *top_exit = nullptr;
+    int top_levels = 0;
+    std::vector<int> h_top_orig;
     // scoring
     float *fit = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
@@ -182,6 +189,45 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
             wx += x;
             wy += y;
             const int b = pf::kd_nearest_ref<PLANAR>(tree, wx, wy, 0.0f);
+            acc += tree.w[b];
+        }
+    }
+    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
+}
+
+// Variant with the top PF_TOP_LEVELS tree levels staged in LDS (48 KB: positions + node ids of 4095 BFS slots).
+// 1024 threads per block, two blocks per CU -> 32 waves/CU share two LDS copies.
+__global__ __launch_bounds__(1024) void k_score_kd_lds(const float *__restrict__ px, const float *__restrict__ py,
+                                                       const float *__restrict__ pth, int n,
+                                                       const float *__restrict__ scan, int nb, int beams_per_chunk,
+                                                       pf::KdView tree, const float2 *__restrict__ top_pos,
+                                                       const int *__restrict__ top_orig, const int *__restrict__ top_exit,
+                                                       int levels, const int *__restrict__ order, int direct,
+                                                       float *__restrict__ out)
+{
+    __shared__ float2 s_pos[PF_TOP_SLOTS + 1];
+    __shared__ int s_orig[PF_TOP_SLOTS + 1];
+    const int nslots = (1 << levels) - 1;
+    for (int k = threadIdx.x; k < nslots; k += 1024) {
+        s_pos[k] = top_pos[k];
+        s_orig[k] = top_orig[k];
+    }
+    __syncthreads();
+    const int slot = blockIdx.x * 1024 + threadIdx.x;
+    const int j0 = blockIdx.y * beams_per_chunk;
+    const int j1 = min(nb, j0 + beams_per_chunk);
+    if (slot >= n) return;
+    const pf::KdTop top{s_pos, s_orig, top_exit, levels};
+    const int i = order ? order[slot] : slot;
+    const float x = px[i], y = py[i], th = pth[i];
+    float acc = 0.0f;
+    for (int j = j0; j < j1; j++) {
+        float wx, wy;
+        pf::clean_lidar_scan(j, scan[j], th, wx, wy);
+        if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
+            wx += x;
+            wy += y;
+            const int b = pf::kd_nearest_ref<true, true>(tree, wx, wy, 0.0f, top);
             acc += tree.w[b];
         }
     }
@@ -329,6 +375,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     CHK(dalloc(&h->scan, (size_t)h->nb));
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
+    CHK(dalloc(&h->top_pos, (size_t)PF_TOP_SLOTS)); CHK(dalloc(&h->top_orig, (size_t)PF_TOP_SLOTS)); CHK(dalloc(&h->top_exit, (size_t)PF_TOP_SLOTS + 1));
     CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
     CHK(dalloc(&h->mkey, n)); CHK(dalloc(&h->mkey2, n)); CHK(dalloc(&h->order, n)); CHK(dalloc(&h->order2, n));
     if (pfslam_sort_pairs_u32(nullptr, &h->sort_tmp_bytes, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, nullptr))
@@ -376,7 +423,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw,
+    void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw, h->top_pos, h->top_orig, h->top_exit,
                     h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->wall_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->new_pts, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
@@ -467,6 +514,63 @@ extern "C" int pfslam_set_variant(pfslam_handle *h, int variant)
     return 0;
 }
 
+// BFS image of the top of the tree for the LDS-staged score kernel.  Staged levels must be complete and have
+// split axis = level % 3 (true for every tree KDTree::Create/InsertNode can produce once it has enough nodes).
+static int refresh_top_exit(pfslam_handle *h)
+{
+    if (h->top_levels <= 0) return 0;
+    const int L = h->top_levels, first_last = (1 << (L - 1)) - 1, n_last = 1 << (L - 1);
+    std::vector<int> ex((size_t)2 * n_last);
+    for (int k = 0; k < n_last; k++) {
+        const pfslam_node &nd = h->h_nodes[h->h_top_orig[first_last + k]];
+        ex[2 * k] = nd.left;
+        ex[2 * k + 1] = nd.right;
+    }
+    HIPCHK(hipMemcpyAsync(h->top_exit, ex.data(), ex.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static int build_top_image(pfslam_handle *h)
+{
+    h->top_levels = 0;
+    const int n = h->kd_size;
+    if (!h->planar || n <= 0) return 0;
+    std::vector<int> orig;
+    orig.reserve(PF_TOP_SLOTS);
+    orig.push_back(0);
+    int levels = 0;
+    for (int lvl = 0; lvl < PF_TOP_LEVELS; lvl++) {
+        const int first = (1 << lvl) - 1, count = 1 << lvl;
+        bool ok = true;
+        for (int k = 0; k < count && ok; k++) ok = h->h_nodes[orig[first + k]].axis == lvl % 3;
+        if (!ok) break;
+        levels = lvl + 1;
+        if (lvl + 1 == PF_TOP_LEVELS) break;
+        bool complete = true; // next level must be complete to be staged too
+        for (int k = 0; k < count && complete; k++) {
+            const pfslam_node &nd = h->h_nodes[orig[first + k]];
+            complete = nd.left >= 0 && nd.right >= 0;
+        }
+        if (!complete) break;
+        for (int k = 0; k < count; k++) {
+            const pfslam_node &nd = h->h_nodes[orig[first + k]];
+            orig.push_back(nd.left);
+            orig.push_back(nd.right);
+        }
+    }
+    if (levels < 6) return 0; // tiny maps: not worth staging
+    const int nslots = (1 << levels) - 1;
+    std::vector<float2> pos((size_t)nslots);
+    for (int k = 0; k < nslots; k++) pos[k] = make_float2(h->h_nodes[orig[k]].x, h->h_nodes[orig[k]].y);
+    orig.resize((size_t)nslots);
+    h->h_top_orig = orig;
+    h->top_levels = levels;
+    HIPCHK(hipMemcpyAsync(h->top_pos, pos.data(), (size_t)nslots * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->top_orig, orig.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return refresh_top_exit(h);
+}
+
 // upload a tree: host mirror + split device layout
 static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
 {
@@ -490,6 +594,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
         if (nd.z != 0.0f) planar = 0;
     }
     h->planar = planar;
+    CHK(build_top_image(h));
     HIPCHK(hipMemcpyAsync(h->hot, hot.data(), (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -611,9 +716,11 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
 // ---- A5 -------------------------------------------------------------------------------------
 static int score_chunks(const pfslam_handle *h)
 {
-    // enough waves to fill 256 CUs x 32 wave slots twice over, never fewer than 8 beams a chunk
+    // ~16 rounds of the 8192 wave slots (256 CUs x 32): fine-grained enough that the tail of the last round is
+    // small (measured: 16 k waves 3.33 ms, 128 k waves 2.9-3.0 ms at 100 k particles); never fewer than 8 beams a chunk
     const int groups = (h->n + 63) / 64;
-    int chunks = (16384 + groups - 1) / groups;
+    static const int target = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 131072;
+    int chunks = (target + groups - 1) / groups;
     chunks = std::max(1, std::min(chunks, (h->nb + 7) / 8));
     return chunks;
 }
@@ -651,7 +758,14 @@ static int launch_score(pfslam_handle *h)
         CHK(timer_pair(h, tp));
         HIPCHK(hipEventRecord(tp.first, h->stream));
     }
-    if (h->planar)
+    // variant 3 = LDS-staged tree top.  Measured on MI355X (100 k particles, 100 k-point map): 2.71 ms vs 2.64 ms for the
+    // plain kernel -- the kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ all SIMD cycles), not L1-bound, and the 16-wave
+    // blocks the 48 KB image needs schedule more coarsely; a persistent-block version was slower still (3.5 ms).
+    const bool use_lds = h->planar && h->top_levels > 0 && h->variant == 3;
+    if (use_lds)
+        hipLaunchKernelGGL(k_score_kd_lds, dim3((h->n + 1023) / 1024, used), dim3(1024), 0, h->stream, h->x, h->y, h->th, h->n,
+                           h->scan, h->nb, bpc, kd_view(h), h->top_pos, h->top_orig, h->top_exit, h->top_levels, order, direct, out);
+    else if (h->planar)
         hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
                            bpc, kd_view(h), order, direct, out);
     else

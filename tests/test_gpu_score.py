@@ -165,3 +165,40 @@ def test_score_at_full_bench_size_properties(gpu):
     assert (bits(h.score_kd()) == bits(fit[perm])).all()
     assert (fit == np.round(fit)).all() and np.abs(fit).max() <= 1081 * 113
     h.close()
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_score_kernel_variants_are_bit_identical(gpu, small_world, variant):
+    """variant 1 = identity lane order, 3 = Morton order + LDS-staged tree top (also after leaf inserts, which touch
+    the exit table below the staged levels)."""
+    base = small_world["tree"]
+    cap = len(base) + 400
+    t = np.zeros(cap, gpu.NODE_DTYPE)
+    t[:len(base)] = base
+    rng = np.random.RandomState(3)
+    for k in range(400):
+        p4 = np.array([np.float32(rng.randint(-700, 700)) * np.float32(0.025), np.float32(rng.randint(-700, 700)) * np.float32(0.025), 0, -100], np.float32)
+        gpu.kd_insert_node(t, len(base) + k, p4)
+    n = 3000
+    p = O.make_particles(n, 0.1, -0.2, 0.3)
+    for f in (1, 2, 3):
+        O.add_noise(p, frame=f)
+    for tree in (base, t):
+        want = O.score_kd(tree, p, small_world["scan"])
+        h = gpu.PfSlam(n, kd_capacity=cap)
+        h.set_variant(variant)
+        h.set_map(tree); h.set_particles(p); h.set_scan(small_world["scan"])
+        assert (bits(h.score_kd()) == bits(want)).all()
+        h.close()
+
+
+def test_lds_variant_through_map_growth(gpu):
+    """Whole steps with the LDS variant: inserts below the staged levels must keep the exit table right."""
+    segs, frames = gpu.synth.corridor_sequence(10, seed=5)
+    a = gpu.PfSlam(400, kd_capacity=1 << 16)
+    b = gpu.PfSlam(400, kd_capacity=1 << 16)
+    b.set_variant(3)
+    for f, (pose, scan) in enumerate(frames, start=1):
+        a.step(f, scan); b.step(f, scan)
+        assert a.trace() == b.trace() and (bits(a.pose) == bits(b.pose)).all()
+    a.close(); b.close()

@@ -57,13 +57,13 @@ static int fail(const std::string &m)
 // ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
-struct HostHeader { // written by the device each step, read back in one D2H
+struct HostHeader { // packed by the device at the end of a step's kernel chain, read back in ONE D2H with the new walls
     int32_t n_wall, n_free, n_new, pad0;
-    float neff, r, r2, pad1;
+    float r, r2, neff, pad1;
     float pose[4];
-    float start[4];
-    int64_t stats[8];
+    int64_t stats[2];
 };
+static_assert(sizeof(HostHeader) == 64, "HostHeader is 64 bytes, the new-wall list follows it");
 
 struct pfslam_handle {
     pfslam_config cfg;
@@ -110,7 +110,7 @@ struct pfslam_handle {
     int *wall_cell = nullptr, *free_cell = nullptr;
     float4 *wall_pts = nullptr, *free_pts = nullptr;
     int *wall_c = nullptr, *free_c = nullptr;
-    float4 *new_pts = nullptr;
+    float4 *new_pts = nullptr; // = d_out + sizeof(HostHeader)
     int *counts = nullptr; // [0] n_wall [1] n_free [2] n_new
     int max_free = 0, max_wall = 0;
     // resample scratch
@@ -122,8 +122,14 @@ struct pfslam_handle {
     int32_t *fit_i = nullptr;
     std::vector<int8_t> h_grid;
     // host mirrors / read-back
-    HostHeader *h_hdr = nullptr; // pinned
-    HostHeader *d_hdr = nullptr;
+    // device->host: [HostHeader | new walls (float4 x max_wall)], one copy per step into pinned memory
+    uint8_t *d_out = nullptr, *h_out = nullptr;
+    size_t out_bytes = 0;
+    // host->device: packed tree updates of a step (new nodes + patched parents), one copy + one scatter kernel
+    uint8_t *d_upd = nullptr, *h_upd = nullptr;
+    size_t upd_bytes = 0;
+    float *h_scan = nullptr; // pinned staging of the scan
+    bool top_exit_stale = false;
     std::vector<pfslam_particle> h_particles;
     std::vector<float> h_tmp;
     std::vector<float4> h_new;
@@ -390,7 +396,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     CHK(dalloc(&h->wall_cell, (size_t)h->max_wall)); CHK(dalloc(&h->free_cell, (size_t)h->max_free));
     CHK(dalloc(&h->wall_pts, (size_t)h->max_wall)); CHK(dalloc(&h->free_pts, (size_t)h->max_free));
     CHK(dalloc(&h->wall_c, (size_t)h->max_wall)); CHK(dalloc(&h->free_c, (size_t)h->max_free));
-    CHK(dalloc(&h->new_pts, (size_t)h->max_wall)); CHK(dalloc(&h->counts, 8));
+    CHK(dalloc(&h->counts, 8));
     const size_t G = (size_t)h->gn;
     const size_t nt_sum = (G + PF_SUM_TILE - 1) / PF_SUM_TILE, nt_scan = (G + PF_SCAN_TILE - 1) / PF_SCAN_TILE;
     CHK(dalloc(&h->tile_r, nt_sum)); CHK(dalloc(&h->tile_r2, nt_sum)); CHK(dalloc(&h->sums, 4));
@@ -398,9 +404,15 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     CHK(dalloc(&h->tile_tot, nt_scan)); CHK(dalloc(&h->tile_off, nt_scan)); CHK(dalloc(&h->tile_pmax, nt_scan));
     CHK(dalloc(&h->src, n));
     CHK(dalloc(&h->grid, M));
-    CHK(dalloc(&h->d_hdr, 1));
-    HIPCHK(hipHostMalloc((void **)&h->h_hdr, sizeof(HostHeader)));
-    memset(h->h_hdr, 0, sizeof(HostHeader));
+    h->out_bytes = sizeof(HostHeader) + (size_t)h->max_wall * 16;
+    CHK(dalloc(&h->d_out, h->out_bytes));
+    h->new_pts = (float4 *)(h->d_out + sizeof(HostHeader));
+    HIPCHK(hipHostMalloc((void **)&h->h_out, h->out_bytes));
+    memset(h->h_out, 0, h->out_bytes);
+    h->upd_bytes = 64 + (size_t)h->max_wall * (16 + 4 + 4 + 4 + 4 + 16);
+    CHK(dalloc(&h->d_upd, h->upd_bytes));
+    HIPCHK(hipHostMalloc((void **)&h->h_upd, h->upd_bytes));
+    HIPCHK(hipHostMalloc((void **)&h->h_scan, (size_t)h->nb * 4));
     h->h_nodes.reserve(1024);
     // particleFilterInit (kernel.cu:122-132): grid = -100, particles at the origin with w = 1, robotPos = 0
     std::vector<float> ones(n, 1.0f);
@@ -426,14 +438,16 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw, h->top_pos, h->top_orig, h->top_exit,
                     h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->wall_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
-                    h->wall_c, h->free_c, h->new_pts, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
-                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_hdr};
+                    h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
+                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_out, h->d_upd};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_global) {
         (void)hipFree(h->gw); (void)hipFree(h->gx); (void)hipFree(h->gy); (void)hipFree(h->gth);
     }
-    if (h->h_hdr) (void)hipHostFree(h->h_hdr);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->h_upd) (void)hipHostFree(h->h_upd);
+    if (h->h_scan) (void)hipHostFree(h->h_scan);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -762,6 +776,10 @@ static int launch_score(pfslam_handle *h)
     // plain kernel -- the kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ all SIMD cycles), not L1-bound, and the 16-wave
     // blocks the 48 KB image needs schedule more coarsely; a persistent-block version was slower still (3.5 ms).
     const bool use_lds = h->planar && h->top_levels > 0 && h->variant == 3;
+    if (use_lds && h->top_exit_stale) {
+        CHK(refresh_top_exit(h));
+        h->top_exit_stale = false;
+    }
     if (use_lds)
         hipLaunchKernelGGL(k_score_kd_lds, dim3((h->n + 1023) / 1024, used), dim3(1024), 0, h->stream, h->x, h->y, h->th, h->n,
                            h->scan, h->nb, bpc, kd_view(h), h->top_pos, h->top_orig, h->top_exit, h->top_levels, order, direct, out);

@@ -389,7 +389,8 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     HIPCHK(hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
     CHK(dalloc(&h->stats, 8)); CHK(dalloc(&h->pose, 4)); CHK(dalloc(&h->start, 4));
     CHK(dalloc(&h->icp_tar, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_cor, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_dbg, 32));
-    CHK(dalloc(&h->free_mask, M)); CHK(dalloc(&h->wall_mask, M));
+    CHK(dalloc(&h->free_mask, 2 * M)); // the two masks are contiguous: one memset per frame
+    h->wall_mask = h->free_mask + M;
     h->max_wall = h->nb;
     h->max_free = (int)std::min<size_t>(M, (size_t)h->nb * (size_t)std::max(h->dimx, h->dimy));
     CHK(dalloc(&h->blk_cnt, 2 * ((M + 4095) / 4096) + 8));
@@ -437,7 +438,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw, h->top_pos, h->top_orig, h->top_exit,
                     h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
-                    h->free_mask, h->wall_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
+                    h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
                     h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_out, h->d_upd};
     for (void *b : bufs)

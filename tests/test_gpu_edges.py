@@ -1,0 +1,106 @@
+"""Edge cases of the domain on the GPU path: NaN / Inf / negative ranges, duplicate map points (collisions),
+single-particle and million-particle handles, missing map, capacity limits -- against the oracle where it applies."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+def test_nan_inf_negative_ranges(pkg, small_world):
+    tree = small_world["tree"]
+    scan = small_world["scan"].copy()
+    scan[::7] = np.nan
+    scan[3::11] = np.inf
+    scan[5::13] = -np.inf
+    scan[2::17] = -3.5          # a negative range is a valid number for the reference: it points backwards
+    n = 200
+    p = O.make_particles(n, 0.2, 0.1, -0.7)
+    O.add_noise(p, 4)
+    h = pkg.PfSlam(n, kd_capacity=len(tree) + 4000)
+    h.set_map(tree); h.set_particles(p); h.set_scan(scan)
+    assert (bits(h.score_kd()) == bits(O.score_kd(tree, p, scan))).all()
+    # the same scan through the map update: rejected beams mark nothing
+    h.set_pose((0.2, 0.1, -0.7))
+    h.update_map_kd()
+    fm, wm = O.get_walls(scan, 800, 800, np.float32(-0.7))
+    assert (h.cells(0) == np.flatnonzero(wm)).all() and (h.cells(1) == np.flatnonzero(fm)).all()
+    h.close()
+
+
+def test_duplicate_map_points_and_exact_hits(pkg):
+    """Collisions: the same point many times (ties in every sort), and queries that coincide with nodes (s == 0)."""
+    rng = np.random.RandomState(2)
+    base = np.zeros((300, 4), np.float32)
+    base[:, 0] = rng.randint(-40, 40, 300).astype(np.float32) * np.float32(0.025)
+    base[:, 1] = rng.randint(-40, 40, 300).astype(np.float32) * np.float32(0.025)
+    pts = np.concatenate([base, base[:150], base[:50], base[:50]])
+    pts[:, 3] = rng.randint(-100, 114, len(pts))
+    tree = pkg.kd_create(pts)
+    assert tree.tobytes() == O.kd_create(pts).tobytes()
+    q = np.zeros((len(pts) + 500, 3), np.float32)
+    q[:len(pts), :2] = pts[:, :2]
+    q[len(pts):, :2] = rng.uniform(-1.2, 1.2, (500, 2))
+    h = pkg.PfSlam(64, kd_capacity=4096)
+    h.set_map(tree)
+    want, _ = O.traverse_batch(tree, q)
+    assert (h.traverse(q) == want).all()
+    h.close()
+
+
+def test_single_particle_and_missing_map(pkg, small_world):
+    h = pkg.PfSlam(1)
+    with pytest.raises(pkg.PfSlamError):
+        h.set_scan(small_world["scan"]); h.score_kd()          # no map loaded: loud error
+    h.set_map(small_world["tree"])
+    p = O.make_particles(1, 0.3, 0.3, 0.3)
+    h.set_particles(p)
+    assert (bits(h.score_kd()) == bits(O.score_kd(small_world["tree"], p, small_world["scan"]))).all()
+    best, fmin, fmax = h.measurement_update()
+    assert best == 0 and fmin == fmax
+    did, neff = h.resample(1)
+    assert did == 0 and neff == 1.0
+    h.close()
+    with pytest.raises(pkg.PfSlamError):
+        pkg.PfSlam(0)
+    with pytest.raises(pkg.PfSlamError):
+        big = np.zeros(100, pkg.NODE_DTYPE)
+        big["left"] = big["right"] = big["parent"] = -1
+        g = pkg.PfSlam(8, kd_capacity=10)
+        g.set_map(big)                                          # larger than kd_capacity
+
+
+def test_one_million_particles(pkg, small_world):
+    """Maximum bench size: 1 M particles in one handle.  Sampled parity + permutation invariance + exact Neff path."""
+    tree, scan = small_world["tree"], small_world["scan"]
+    n = 1 << 20
+    p = O.make_particles(n, 0.1, -0.2, 0.3)
+    rng = np.random.RandomState(0)
+    p["x"] += rng.normal(0, 0.03, n).astype(np.float32)
+    p["y"] += rng.normal(0, 0.03, n).astype(np.float32)
+    p["theta"] += rng.normal(0, 0.02, n).astype(np.float32)
+    h = pkg.PfSlam(n)
+    h.set_map(tree); h.set_particles(p); h.set_scan(scan)
+    fit = h.score_kd()
+    sub = rng.choice(n, 96, replace=False)
+    assert (bits(fit[sub]) == bits(O.score_kd(tree, p[sub], scan))).all()
+    best, fmin, fmax = h.measurement_update()
+    assert best == int(np.argmax(fit)) and fmin == fit.min() and fmax == fit.max()
+    did, neff = h.resample(3)
+    w = h.particles()["w"] if not did else None
+    # canonical Neff over 256 tiles equals the oracle's
+    import ctypes as C
+    pw = p.copy()
+    O.lib().orc_update_weights_f32(O.P(pw), n, O.P(fit), float(np.float32(1) / (np.float32(fmax) - np.float32(fmin))), int(fmin))
+    ne = C.c_float()
+    did_o = O.lib().orc_resample(O.P(pw), n, 3, C.byref(ne), None)
+    assert did == did_o and np.float32(neff) == np.float32(ne.value)
+    if did:
+        got = h.particles()
+        assert (bits(got["x"]) == bits(pw["x"])).all() and (bits(got["theta"]) == bits(pw["theta"])).all()
+    h.close()

@@ -159,6 +159,93 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
     return bestIdx;
 }
 
+// Two independent queries per lane, interleaved (ILP 2): the traversal is a chain of dependent L1 gathers and the
+// score kernel is latency-bound at the hardware limit of 8 waves per SIMD (halving the occupancy doubles its time),
+// so a second query per lane is the remaining way to put more loads in flight.  Semantics per query are exactly
+// kd_nearest_ref<true>'s; a query with valid == false is skipped.
+struct KdQuery {
+    float px, py, sBest, sGuard;
+    int bestIdx, prevBest, head;
+};
+
+__device__ __forceinline__ void kd_visit_planar(KdQuery &q, const uint4 nd, const bool active, bool &inBand)
+{
+    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+    const float dx = nx - q.px, dy = ny - q.py;
+    const float s = dx * dx + dy * dy;
+    const bool take = active & (s < q.sGuard);
+    inBand = active & (s < q.sBest) & !take;
+    q.sBest = take ? s : q.sBest;
+    q.sGuard = take ? s * PF_GUARD_K : q.sGuard;
+    q.bestIdx = take ? q.head : q.bestIdx;
+    const uint32_t axis = nd.z >> 30;
+    const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
+    const bool lt = (pa < na) & (axis < 2);
+    const int next = lt ? (int)(nd.z & 0x3fffffffu) - 1 : (int)nd.w;
+    q.head = active ? next : q.head;
+}
+
+// the rare guard-band case of one visit, resolved exactly (see kd_nearest_ref)
+__device__ __forceinline__ void kd_band_fix(KdQuery &q, const uint4 nd, const int visited, const bool inBand)
+{
+    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+    const float dx = nx - q.px, dy = ny - q.py;
+    float s = dx * dx + dy * dy, sb = q.sBest;
+    asm volatile("" : "+v"(sb));
+    const bool take = inBand && fsqrt(s) < fsqrt(sb);
+    q.sBest = take ? s : q.sBest;
+    q.sGuard = take ? s * PF_GUARD_K : q.sGuard;
+    q.bestIdx = take ? visited : q.bestIdx;
+}
+
+// end of a descent: nodeFullyExplored test + parent hyperplane check; sets head to the far child or leaves it < 0
+// and returns whether the query is finished
+__device__ __forceinline__ bool kd_after_descent_planar(const KdView &t, KdQuery &q)
+{
+    if (q.bestIdx == q.prevBest) return true;
+    q.prevBest = q.bestIdx;
+    const float bestDist = fsqrt(q.sBest);
+    const int pi = t.parent[q.bestIdx];
+    if (pi < 0) return true; // H1
+    const uint4 nd = t.hot[pi];
+    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+    const uint32_t axis = nd.z >> 30;
+    const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
+    const float hd = axis < 2 ? fabsf(pa - na) : 0.0f;
+    const bool lt = (pa < na) & (axis < 2);
+    if (!(hd < bestDist)) return true;
+    q.head = lt ? (int)nd.w : (int)(nd.z & 0x3fffffffu) - 1;
+    return false; // an empty far side (head < 0) ends at the next after-descent test (best unchanged)
+}
+
+__device__ __forceinline__ void kd_nearest_ref_x2(const KdView &t, KdQuery &a, KdQuery &b, bool doneA, bool doneB)
+{
+    a.sBest = a.sGuard = b.sBest = b.sGuard = INFINITY;
+    a.bestIdx = b.bestIdx = 0;
+    a.prevBest = b.prevBest = -1;
+    a.head = doneA ? -1 : 0;
+    b.head = doneB ? -1 : 0;
+    for (;;) {
+        for (;;) {
+            const bool actA = a.head >= 0, actB = b.head >= 0;
+            if (!(actA | actB)) break;
+            const int ia = actA ? a.head : 0, ib = actB ? b.head : 0;
+            const uint4 ndA = t.hot[ia];
+            const uint4 ndB = t.hot[ib];
+            bool bandA, bandB;
+            kd_visit_planar(a, ndA, actA, bandA);
+            kd_visit_planar(b, ndB, actB, bandB);
+            if (__builtin_amdgcn_ballot_w64(bandA | bandB) != 0ull) {
+                kd_band_fix(a, ndA, ia, bandA);
+                kd_band_fix(b, ndB, ib, bandB);
+            }
+        }
+        if (!doneA) doneA = kd_after_descent_planar(t, a);
+        if (!doneB) doneB = kd_after_descent_planar(t, b);
+        if (doneA & doneB) break;
+    }
+}
+
 // LIDAR_ANGLE(i) (kernel.cu:42) + CleanLidarScan (kernel.cu:182-187)
 __device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)
 {

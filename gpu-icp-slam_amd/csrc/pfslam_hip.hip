@@ -201,6 +201,43 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
 }
 
+// ILP-2 variant: each lane interleaves the traversals of two consecutive beams (planar maps).
+__global__ __launch_bounds__(256) void k_score_kd_x2(const float *__restrict__ px, const float *__restrict__ py,
+                                                     const float *__restrict__ pth, int n,
+                                                     const float *__restrict__ scan, int nb, int beams_per_chunk,
+                                                     pf::KdView tree, const int *__restrict__ order, int direct,
+                                                     float *__restrict__ out)
+{
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * beams_per_chunk;
+    const int j1 = min(nb, j0 + beams_per_chunk);
+    if (slot >= n) return;
+    const int i = order ? order[slot] : slot;
+    const float x = px[i], y = py[i], th = pth[i];
+    float acc = 0.0f;
+    for (int j = j0; j < j1; j += 2) {
+        pf::KdQuery qa, qb;
+        float wx, wy;
+        pf::clean_lidar_scan(j, scan[j], th, wx, wy);
+        const bool va = fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE;
+        qa.px = wx + x;
+        qa.py = wy + y;
+        bool vb = false;
+        qb.px = qb.py = 0.0f;
+        if (j + 1 < j1) {
+            pf::clean_lidar_scan(j + 1, scan[j + 1], th, wx, wy);
+            vb = fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE;
+            qb.px = wx + x;
+            qb.py = wy + y;
+        }
+        pf::kd_nearest_ref_x2(tree, qa, qb, !va, !vb);
+        // beam order of the sum is kept: j, then j+1
+        if (va) acc += tree.w[qa.bestIdx];
+        if (vb) acc += tree.w[qb.bestIdx];
+    }
+    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
+}
+
 // Variant with the top PF_TOP_LEVELS tree levels staged in LDS (48 KB: positions + node ids of 4095 BFS slots).
 // 1024 threads per block, two blocks per CU -> 32 waves/CU share two LDS copies.
 __global__ __launch_bounds__(1024) void k_score_kd_lds(const float *__restrict__ px, const float *__restrict__ py,
@@ -784,9 +821,15 @@ static int launch_score(pfslam_handle *h)
     if (use_lds)
         hipLaunchKernelGGL(k_score_kd_lds, dim3((h->n + 1023) / 1024, used), dim3(1024), 0, h->stream, h->x, h->y, h->th, h->n,
                            h->scan, h->nb, bpc, kd_view(h), h->top_pos, h->top_orig, h->top_exit, h->top_levels, order, direct, out);
-    else if (h->planar)
-        hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
+    else if (h->planar && h->variant == 4)
+        hipLaunchKernelGGL(k_score_kd_x2, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                           kd_view(h), order, direct, out);
+    else if (h->planar) {
+        // PFSLAM_DBG_LDS: pad the launch with dynamic LDS to cap the occupancy (bound-ness experiments only)
+        static const int dbg_lds = getenv("PFSLAM_DBG_LDS") ? atoi(getenv("PFSLAM_DBG_LDS")) : 0;
+        hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), dbg_lds, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
                            bpc, kd_view(h), order, direct, out);
+    }
     else
         hipLaunchKernelGGL(k_score_kd<false>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
                            bpc, kd_view(h), order, direct, out);

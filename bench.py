@@ -70,6 +70,49 @@ def cpu_baseline(O, tree, particles, scan, sample):
     }, visits / max(valid, 1), valid / one
 
 
+def extras(pkg, O, tree, pts, scan, device):
+    """Side measurements for DESIGN.md (not part of the contract line's metric): the host map structure next to the
+    reference's own kdtree.cpp (oracle/_ref, kind "reference"), and the 2-D grid scoring path (BASELINE configs[0-1])."""
+    ex = {}
+    try:
+        t0 = time.perf_counter(); pkg.kd_create(pts); t1 = time.perf_counter() - t0
+        ex["kd_create_100k_ms"] = {"product_host": t1 * 1e3}
+        ref = O.ref_kdtree()
+        if ref is not None:
+            buf = np.zeros(len(pts), O.NODE_DTYPE)
+            t0 = time.perf_counter(); ref.ref_kd_create(O.P(pts), len(pts), O.P(buf)); t2 = time.perf_counter() - t0
+            ex["kd_create_100k_ms"]["reference_kdtree_cpp"] = t2 * 1e3
+            ex["kd_create_100k_ms"]["identical_output"] = bool(buf.tobytes() == pkg.kd_create(pts).tobytes())
+        # grid path: 10 k particles, 1600x1600 int8 grid rasterised from the same walls
+        n = 10000
+        grid = np.full((1600, 1600), -100, np.int8)
+        gx = np.clip(np.round(800 + pts[:, 0] / 0.025).astype(int), 0, 1599); gy = np.clip(np.round(800 + pts[:, 1] / 0.025).astype(int), 0, 1599)
+        grid[gx, gy] = 113
+        h = pkg.PfSlam(n, device=device)
+        p = O.make_particles(n); O.add_noise(p, 1)
+        h.set_grid(grid); h.set_particles(p); h.set_scan(scan)
+        h.score_grid(); h.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            h.L.pfslam_score_grid(h._h, None)
+        h.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        fit = h.score_grid()
+        want = np.zeros(256, np.int32)
+        import ctypes as C
+        patch = O.default_patch()
+        O.lib().orc_score_grid(O.P(grid), 1600, 1600, C.byref(patch), O.P(p[:256].copy()), 256, O.P(scan), 1081, O.P(want))
+        t0 = time.perf_counter()
+        O.lib().orc_score_grid(O.P(grid), 1600, 1600, C.byref(patch), O.P(p[:2048].copy()), 2048, O.P(scan), 1081, O.P(np.zeros(2048, np.int32)))
+        tc = time.perf_counter() - t0
+        ex["grid_path_10k_particles"] = {"gpu_evals_per_s": n / dt, "ms_per_call_incl_minmax_weights": dt * 1e3,
+                                         "cpu_oracle_1thread_evals_per_s": 2048 / tc, "parity_sample_ok": bool((fit[:256] == want).all())}
+        h.close()
+    except Exception as e:  # extras must never break the contract line
+        ex["error"] = repr(e)
+    return ex
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -186,6 +229,7 @@ def main():
                                "kernel_evals_per_s": n_local / (kern_ms * 1e-3),
                                "note": "algorithmic node bytes are served from L2/L1 (the 1.6 MB hot tree is cache "
                                        "resident); compulsory HBM traffic is ~20 B/eval, hence frac can exceed 1"}
+            out["extras"] = extras(pkg, O, tree, pts, scans[0], local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

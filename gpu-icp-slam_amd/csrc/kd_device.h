@@ -8,9 +8,6 @@
 #pragma once
 #include "pf_math.h"
 
-#ifndef PF_LAZY_SQRT
-#define PF_LAZY_SQRT 2
-#endif
 
 namespace pf {
 

@@ -132,7 +132,6 @@ struct pfslam_handle {
     bool top_exit_stale = false;
     std::vector<pfslam_particle> h_particles;
     std::vector<float> h_tmp;
-    std::vector<float4> h_new;
     int32_t trace[8] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // live timing of the dominant kernel inside pfslam_step (bench.py roofline leg)

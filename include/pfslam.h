@@ -144,7 +144,8 @@ int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
  * launch; pfslam_get_timers -> [total ms, launches, 0, 0].  pfslam_set_timing also resets the accumulators. */
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[4]);
-/* which scoring kernel variant to run: 0 = auto, 1 = global-memory nodes, 2 = LDS-staged tree top */
+/* scoring kernel variant (all bit-identical; for A/B measurements): 0 = default (Morton-ordered lanes), 1 = identity lane
+ * order, 3 = Morton + LDS-staged tree top, 4 = Morton + two interleaved beams per lane */
 int pfslam_set_variant(pfslam_handle *h, int variant);
 
 /* ---- debug: evaluate the bit-reproducible math specification (pf_math.h) on the device.

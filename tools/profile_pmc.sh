@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_profile_pmc.sh "<counters>" tag   (run on the GPU box from the repo root)
+# usage: profile_pmc.sh "<counters>" tag   (run on the GPU box from the repo root)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 rocprofv3 --pmc $1 -d gpurun_out/prof/$2 -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline ${3:-} > gpurun_out/prof/$2.log 2>&1

@@ -12,11 +12,17 @@
 namespace pf {
 
 struct KdView {
-    const uint4 *hot;   // {x bits, y bits, (left+1) | axis<<30, right}
-    const float *z;     // node z (all zero for a planar map)
+    const uint4 *hot;   // {x bits, y bits, left (30-bit two's complement) | axis<<30, right}
+    const float *z;     // node z; for a PLANAR map (all z == 0): the true left child of z-level nodes, as int bits
     const int *parent;  // parent index, -1 at the root
     const float *w;     // occupancy weight (Node.value.w)
+    int planar;         // every node has z == 0
 };
+
+// In a planar map a z-level node (axis 2) always sends the query right (0 < 0 is false).  Its hot record therefore
+// stores the RIGHT child in both link fields -- the descent needs no axis test -- and the true left child, which only
+// the parent-hyperplane re-descent can reach, moves to the (otherwise all-zero) z side array.
+__host__ __device__ __forceinline__ int hot_left(uint32_t la) { return ((int)(la << 2)) >> 2; } // sign-extend 30 bits
 
 // Top of the tree staged in LDS (planar maps): the first `levels` levels in BFS order (slot 0 = root,
 // children of slot s = 2s+1, 2s+2), which a median-split tree always fills completely and whose split
@@ -28,8 +34,9 @@ struct KdTop {
     int levels;
 };
 
-__host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, int left, int right)
+__host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, int left, int right, bool planar)
 {
+    if (planar && axis == 2) left = right;
     uint4 r;
 #if defined(__HIP_DEVICE_COMPILE__)
     r.x = __float_as_uint(x);
@@ -39,7 +46,7 @@ __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, i
     a.f = x; b.f = y;
     r.x = a.u; r.y = b.u;
 #endif
-    r.z = (uint32_t)(left + 1) | ((uint32_t)axis << 30);
+    r.z = ((uint32_t)left & 0x3fffffffu) | ((uint32_t)axis << 30);
     r.w = (uint32_t)right;
     return r;
 }
@@ -95,8 +102,11 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             const float dx = nx - px, dy = ny - py;
             float s = dx * dx + dy * dy;
             float nz = 0.0f;
+            int zleft = 0; // generic kernel on a planar map (query with z != 0): the z array holds z-level left children
             if (!PLANAR) {
-                nz = t.z[head];
+                const float zraw = t.z[head];
+                nz = t.planar ? 0.0f : zraw;
+                zleft = __float_as_int(zraw);
                 const float dz = nz - pz;
                 s = s + dz * dz;
             }
@@ -106,7 +116,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             // (The relative bound needs normal floats: it assumes two DISTINCT map points are never both within
             // 1e-15 m of a query, i.e. squared distances below 1e-30 occur only for exact coincidence, s == 0.)
             bool take = s < sGuard;
-            const bool inBand = (s < sBest) & !take;
+            const bool inBand = (s < sBest) != take; // sGuard < sBest, so this is "sGuard <= s < sBest"
             if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) { // wave-uniform, almost never taken
                 float sb = sBest;
                 asm volatile("" : "+v"(sb)); // pins the two sqrt inside the branch (the compiler would speculate them)
@@ -117,15 +127,14 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             bestIdx = take ? head : bestIdx;
             const uint32_t axis = nd.z >> 30;
             float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;
-            bool lt;
-            if (PLANAR) {
-                lt = (pa < na) & (axis < 2); // z levels: 0 < 0 is false -> right
-            } else {
+            if (!PLANAR) {
                 pa = axis == 2 ? pz : pa;
                 na = axis == 2 ? nz : na;
-                lt = pa < na;
             }
-            head = lt ? (int)(nd.z & 0x3fffffffu) - 1 : (int)nd.w;
+            const bool lt = pa < na; // PLANAR z levels: both links hold the right child
+            int left = hot_left(nd.z);
+            if (!PLANAR) left = (t.planar && axis == 2) ? zleft : left;
+            head = lt ? left : (int)nd.w;
         }
         // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
         if (bestIdx == prevBest) break;
@@ -139,19 +148,23 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;
         float hd;
         bool lt;
+        int left = hot_left(nd.z);
         if (PLANAR) {
             hd = axis < 2 ? fabsf(pa - na) : 0.0f;
             lt = (pa < na) & (axis < 2);
+            if (axis == 2) left = __float_as_int(t.z[pi]); // true left of a planar z-level node
         } else {
             if (axis == 2) {
+                const float zraw = t.z[pi];
                 pa = pz;
-                na = t.z[pi];
+                na = t.planar ? 0.0f : zraw;
+                if (t.planar) left = __float_as_int(zraw);
             }
             hd = fabsf(pa - na);
             lt = pa < na;
         }
         if (!(hd < bestDist)) break;
-        head = lt ? (int)nd.w : (int)(nd.z & 0x3fffffffu) - 1; // the side the query is NOT on
+        head = lt ? (int)nd.w : left; // the side the query is NOT on
     }
     return bestIdx;
 }
@@ -177,8 +190,8 @@ __device__ __forceinline__ void kd_visit_planar(KdQuery &q, const uint4 nd, cons
     q.bestIdx = take ? q.head : q.bestIdx;
     const uint32_t axis = nd.z >> 30;
     const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
-    const bool lt = (pa < na) & (axis < 2);
-    const int next = lt ? (int)(nd.z & 0x3fffffffu) - 1 : (int)nd.w;
+    const bool lt = pa < na;
+    const int next = lt ? hot_left(nd.z) : (int)nd.w;
     q.head = active ? next : q.head;
 }
 
@@ -211,7 +224,7 @@ __device__ __forceinline__ bool kd_after_descent_planar(const KdView &t, KdQuery
     const float hd = axis < 2 ? fabsf(pa - na) : 0.0f;
     const bool lt = (pa < na) & (axis < 2);
     if (!(hd < bestDist)) return true;
-    q.head = lt ? (int)nd.w : (int)(nd.z & 0x3fffffffu) - 1;
+    q.head = lt ? (int)nd.w : (axis == 2 ? __float_as_int(t.z[pi]) : hot_left(nd.z));
     return false; // an empty far side (head < 0) ends at the next after-descent test (best unchanged)
 }
 

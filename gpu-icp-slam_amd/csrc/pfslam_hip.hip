@@ -378,7 +378,7 @@ static int dalloc(T **p, size_t count)
     return 0;
 }
 
-static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw}; }
+static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw, h->planar}; }
 
 extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
 {
@@ -446,7 +446,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     h->new_pts = (float4 *)(h->d_out + sizeof(HostHeader));
     HIPCHK(hipHostMalloc((void **)&h->h_out, h->out_bytes));
     memset(h->h_out, 0, h->out_bytes);
-    h->upd_bytes = 64 + (size_t)h->max_wall * (16 + 4 + 4 + 4 + 4 + 16);
+    h->upd_bytes = 64 + (size_t)((h->max_wall + 3) & ~3) * (16 + 4 + 4 + 4 + 4 + 16 + 4);
     CHK(dalloc(&h->d_upd, h->upd_bytes));
     HIPCHK(hipHostMalloc((void **)&h->h_upd, h->upd_bytes));
     HIPCHK(hipHostMalloc((void **)&h->h_scan, (size_t)h->nb * 4));
@@ -638,11 +638,15 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
         if (nd.axis < 0 || nd.axis > 2 || nd.left < -1 || nd.left >= n || nd.right < -1 || nd.right >= n ||
             nd.parent < -1 || nd.parent >= n)
             return fail("pfslam_set_map: node " + std::to_string(i) + " has out-of-range links or axis");
-        hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right);
         par[i] = nd.parent;
         z[i] = nd.z;
         w[i] = nd.w;
         if (nd.z != 0.0f) planar = 0;
+    }
+    for (int i = 0; i < n; i++) {
+        const pfslam_node &nd = nodes[i];
+        hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right, planar != 0);
+        if (planar && nd.axis == 2) memcpy(&z[i], &nd.left, 4); // true left child of a planar z-level node
     }
     h->planar = planar;
     CHK(build_top_image(h));

@@ -104,3 +104,17 @@ def test_one_million_particles(pkg, small_world):
         got = h.particles()
         assert (bits(got["x"]) == bits(pw["x"])).all() and (bits(got["theta"]) == bits(pw["theta"])).all()
     h.close()
+
+
+def test_3d_queries_on_a_planar_map(pkg, small_world):
+    """pfslam_traverse with z != 0 queries against a planar map takes the generic kernel, which has to undo the
+    planar link trick of the device layout."""
+    tree = small_world["tree"]
+    rng = np.random.RandomState(11)
+    q = rng.uniform(-15, 15, (5000, 3)).astype(np.float32)
+    q[:, 2] = rng.uniform(-0.5, 0.5, 5000)
+    h = pkg.PfSlam(64, kd_capacity=len(tree) + 64)
+    h.set_map(tree)
+    want, _ = O.traverse_batch(tree, q)
+    assert (h.traverse(q) == want).all()
+    h.close()

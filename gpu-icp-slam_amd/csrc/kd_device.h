@@ -98,6 +98,10 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
     for (;;) {
         while (head >= 0) { // greedy descent
             const uint4 nd = t.hot[head];
+#ifdef PF_EXP_EXTRA_LOAD /* bound-ness experiment: a second 16-byte gather per visit, kept alive through sGuard's NaN-ness */
+            const uint4 nd2 = t.hot[head ^ 1];
+            if (nd2.x == 0x7fc12345u) sGuard = 0.0f;
+#endif
             const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
             const float dx = nx - px, dy = ny - py;
             float s = dx * dx + dy * dy;

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend gloo)")
     return ap.parse_args()
 
 
@@ -117,7 +119,7 @@ def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(a.gpus, 1):
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
@@ -133,7 +135,10 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     # ---- synthetic workload (identical on every rank) -------------------------------------------
     n_local = a.particles

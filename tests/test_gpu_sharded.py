@@ -99,3 +99,56 @@ def test_sharded_wrapper_world1_equals_plain_step(pkg):
         assert (bits(pa[fld]) == bits(ps[fld])).all()
     assert a.map().tobytes() == s.eng.map().tobytes()
     a.close(); s.eng.close()
+
+
+def _mp_worker(rank, world, port, n_global, n_frames, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("gpu-icp-slam_amd")
+    sharded = importlib.import_module("gpu-icp-slam_amd.sharded")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = sharded.ShardedSlam(pkg, n_global, rank, world, device=0, dist=dist, torch=torch, kd_capacity=1 << 16)
+    segs, frames = pkg.synth.corridor_sequence(n_frames, seed=5)
+    poses = []
+    for f, (pose, scan) in enumerate(frames, start=1):
+        s.step(f, scan)
+        poses.append(s.pose.view(np.int32).tolist())
+    s.synchronize()
+    p = s.eng.particles()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=p["x"], y=p["y"], th=p["theta"], w=p["w"], poses=np.array(poses),
+             tree=s.eng.map().view(np.uint8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_gloo_match_single_handle(tmp_path, pkg):
+    """The real multi-process path (ShardedSlam over torch.distributed) with both ranks on GPU 0 and gloo carrying the
+    collectives: bit-identical to the single-handle step.  (RCCL itself needs one GPU per rank.)"""
+    import os
+    import socket
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    n_global, n_frames, world = 800, 10, 2
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    mp.spawn(_mp_worker, args=(world, port, n_global, n_frames, str(tmp_path)), nprocs=world, join=True)
+    a = pkg.PfSlam(n_global, kd_capacity=1 << 16)
+    segs, frames = pkg.synth.corridor_sequence(n_frames, seed=5)
+    poses = []
+    for f, (pose, scan) in enumerate(frames, start=1):
+        a.step(f, scan)
+        poses.append(a.pose.view(np.int32).tolist())
+    want = a.particles()
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    for k in range(world):
+        assert r[k]["poses"].tolist() == poses
+        assert r[k]["tree"].tobytes() == a.map().tobytes()
+    for fld, key in (("x", "x"), ("y", "y"), ("theta", "th"), ("w", "w")):
+        assert (bits(np.concatenate([r[k][key] for k in range(world)])) == bits(want[fld])).all(), fld
+    a.close()

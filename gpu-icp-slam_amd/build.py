@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

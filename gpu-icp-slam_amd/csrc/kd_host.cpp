@@ -9,6 +9,7 @@
 #include "../../include/pfslam.h"
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -17,7 +18,10 @@ inline bool byX(const Pt &a, const Pt &b) { return a.x < b.x; }
 inline bool byY(const Pt &a, const Pt &b) { return a.y < b.y; }
 inline bool byZ(const Pt &a, const Pt &b) { return a.z < b.z; }
 
-void build_range(std::vector<Pt> &buf, int lo, int hi, pfslam_node *out, int idx, int parent)
+// `fork` > 0: the two sub-ranges are disjoint slices of `buf` and disjoint slices of `out` (pre-order layout), so
+// they are built on two threads; every sort still sees exactly the sequence the sequential build would give it,
+// hence the same (unstable-sort dependent) topology as the reference.
+void build_range(std::vector<Pt> &buf, int lo, int hi, pfslam_node *out, int idx, int parent, int fork)
 {
     const int axis = parent < 0 ? 0 : (out[parent].axis + 1) % 3;
     auto first = buf.begin() + lo, last = buf.begin() + hi;
@@ -29,14 +33,17 @@ void build_range(std::vector<Pt> &buf, int lo, int hi, pfslam_node *out, int idx
     const int count = hi - lo, mid = count / 2;
     const Pt &m = buf[lo + mid];
     out[idx] = pfslam_node{axis, -1, -1, parent, m.x, m.y, m.z, m.w};
-    if (mid > 0) {
-        out[idx].left = idx + 1;
-        build_range(buf, lo, lo + mid, out, idx + 1, idx);
+    const bool has_left = mid > 0, has_right = mid < count - 1;
+    if (has_left) out[idx].left = idx + 1;
+    if (has_right) out[idx].right = idx + mid + 1;
+    if (fork > 0 && has_left && has_right && count > 8192) {
+        std::thread t([&] { build_range(buf, lo, lo + mid, out, idx + 1, idx, fork - 1); });
+        build_range(buf, lo + mid + 1, hi, out, idx + mid + 1, idx, fork - 1);
+        t.join();
+        return;
     }
-    if (mid < count - 1) {
-        out[idx].right = idx + mid + 1;
-        build_range(buf, lo + mid + 1, hi, out, idx + mid + 1, idx);
-    }
+    if (has_left) build_range(buf, lo, lo + mid, out, idx + 1, idx, 0);
+    if (has_right) build_range(buf, lo + mid + 1, hi, out, idx + mid + 1, idx, 0);
 }
 } // namespace
 
@@ -47,7 +54,8 @@ extern "C" int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out)
     std::vector<Pt> buf(n);
     for (int i = 0; i < n; i++) buf[i] = Pt{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
     std::sort(buf.begin(), buf.end(), byX); // KDTree::Create pre-sorts on x before the recursive sort
-    build_range(buf, 0, n, out, 0, -1);
+    const unsigned hw = std::thread::hardware_concurrency();
+    build_range(buf, 0, n, out, 0, -1, hw >= 16 ? 4 : hw >= 4 ? 2 : hw >= 2 ? 1 : 0); // up to 16 concurrent sub-builds
     return 0;
 }
 

@@ -283,8 +283,17 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
 {
     int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= n) return;
-    float a = partial[slot];
-    for (int c = 1; c < chunks; c++) a += partial[(size_t)c * n + slot];
+    // sequential chunk order (deterministic for any weights); loads are independent, so keep 16 of them in flight
+    float a = 0.0f;
+    int c = 0;
+    for (; c + 16 <= chunks; c += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = partial[(size_t)(c + k) * n + slot];
+#pragma unroll
+        for (int k = 0; k < 16; k++) a += v[k];
+    }
+    for (; c < chunks; c++) a += partial[(size_t)c * n + slot];
     fit[order ? order[slot] : slot] = a;
 }
 
@@ -772,11 +781,11 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
 static int score_chunks(const pfslam_handle *h)
 {
     // ~16 rounds of the 8192 wave slots (256 CUs x 32): fine-grained enough that the tail of the last round is
-    // small (measured: 16 k waves 3.33 ms, 128 k waves 2.9-3.0 ms at 100 k particles); never fewer than 8 beams a chunk
+    // small (measured: 16 k waves 3.33 ms, 128 k waves 2.9-3.0 ms at 100 k particles); down to one beam per chunk for small N
     const int groups = (h->n + 63) / 64;
     static const int target = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 131072;
     int chunks = (target + groups - 1) / groups;
-    chunks = std::max(1, std::min(chunks, (h->nb + 7) / 8));
+    chunks = std::max(1, std::min(chunks, h->nb)); // small particle counts go down to one beam per wave
     return chunks;
 }
 

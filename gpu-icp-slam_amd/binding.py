@@ -23,7 +23,8 @@ SYMBOLS = [
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
-    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size",
+    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
+    "pfslam_check_loop_closure", "pfslam_get_topology",
 ]
 
 
@@ -110,6 +111,10 @@ def load():
     L.pfslam_resample_gather.argtypes = [vp]
     L.pfslam_maybe_balance.argtypes = [vp, i32]
     L.pfslam_kd_size.argtypes = [vp]
+    L.pfslam_topology_update.argtypes = [vp, vp]
+    L.pfslam_find_walls.argtypes = [vp, vp, vp, vp]
+    L.pfslam_check_loop_closure.argtypes = [vp, vp, i32, vp]
+    L.pfslam_get_topology.argtypes = [vp, vp, i32, vp, vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -281,6 +286,30 @@ class PfSlam:
     @property
     def kd_size(self):
         return self.L.pfslam_kd_size(self._h)
+
+    # -- topology graph / loop-closure proposal (kernel.cu:623-795)
+    def topology_update(self):
+        n = C.c_int()
+        _chk(self.L.pfslam_topology_update(self._h, C.byref(n)), "pfslam_topology_update")
+        return n.value
+
+    def find_walls(self, a_xy, b_xy):
+        a = np.ascontiguousarray(a_xy, np.float32); b = np.ascontiguousarray(b_xy, np.float32)
+        n = C.c_int()
+        _chk(self.L.pfslam_find_walls(self._h, _p(a), _p(b), C.byref(n)), "pfslam_find_walls")
+        return n.value
+
+    def check_loop_closure(self, cap=4096):
+        pairs = np.zeros((cap, 2), np.int32)
+        n = C.c_int()
+        _chk(self.L.pfslam_check_loop_closure(self._h, _p(pairs), cap, C.byref(n)), "pfslam_check_loop_closure")
+        return pairs[:min(n.value, cap)].copy()
+
+    def topology(self, cap=4096):
+        nodes = np.zeros((cap, 3), np.float32)
+        n, idx = C.c_int(), C.c_int()
+        _chk(self.L.pfslam_get_topology(self._h, _p(nodes), cap, C.byref(n), C.byref(idx)), "pfslam_get_topology")
+        return nodes[:n.value].copy(), idx.value
 
     def resample_plan(self, frame):
         did, neff = C.c_int(), C.c_float()

@@ -121,6 +121,12 @@ struct pfslam_handle {
     int8_t *grid = nullptr;
     int32_t *fit_i = nullptr;
     std::vector<int8_t> h_grid;
+    // topology graph of cluster 0 (kernel.cu:147-157): node (x, y, dist), adjacency, current node
+    struct TopoNode { float x, y, dist; };
+    std::vector<TopoNode> topo_nodes{TopoNode{0.0f, 0.0f, 0.0f}};
+    std::vector<std::vector<unsigned>> topo_edges{std::vector<unsigned>()};
+    unsigned topo_idx = 0;
+    int *d_count = nullptr;
     // host mirrors / read-back
     // device->host: [HostHeader | new walls (float4 x max_wall)], one copy per step into pinned memory
     uint8_t *d_out = nullptr, *h_out = nullptr;
@@ -450,6 +456,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     CHK(dalloc(&h->tile_tot, nt_scan)); CHK(dalloc(&h->tile_off, nt_scan)); CHK(dalloc(&h->tile_pmax, nt_scan));
     CHK(dalloc(&h->src, n));
     CHK(dalloc(&h->grid, M));
+    CHK(dalloc(&h->d_count, 4));
     h->out_bytes = sizeof(HostHeader) + (size_t)h->max_wall * 16;
     CHK(dalloc(&h->d_out, h->out_bytes));
     h->new_pts = (float4 *)(h->d_out + sizeof(HostHeader));
@@ -485,7 +492,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
                     h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
-                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_out, h->d_upd};
+                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->d_out, h->d_upd};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_global) {

@@ -121,6 +121,21 @@ int pfslam_update_map_grid(pfslam_handle *h);
  * xyz_host: n*3 floats; best_host: n ints */
 int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *best_host);
 
+/* ---- topology graph / loop-closure proposal (UpdateTopology, FindWalls, CheckLoopClosure: kernel.cu:623-795).
+ * The reference leaves both calls commented out of its step (kernel.cu:1750-1751) and discards the clusters it builds
+ * (kernel.cu:776), so these are explicit entry points, not part of pfslam_step.  They act on the current robot pose
+ * and on the 2-D occupancy grid (pfslam_set_grid / pfslam_update_map_grid).
+ * topology_update: adds a graph node when the pose is > 2.5 m from every node; *n_nodes receives the node count.
+ * find_walls: cells with occupancy > 30 on the Bresenham ray between two world points (exact count; the reference's
+ *   CheckVisibility accumulates non-atomically).
+ * check_loop_closure: pairs (candidate node j, visible node k) for every node j closer than 6 m on the map and
+ *   farther than 20 m along the graph; returns the pair count in *n (pairs beyond cap are counted, not written).
+ * get_topology: nodes as (x, y, dist) triples; *node_idx = index of the current node. */
+int pfslam_topology_update(pfslam_handle *h, int *n_nodes);
+int pfslam_find_walls(pfslam_handle *h, const float a_xy[2], const float b_xy[2], int *n_walls);
+int pfslam_check_loop_closure(pfslam_handle *h, int32_t *pairs, int cap, int *n);
+int pfslam_get_topology(pfslam_handle *h, float *nodes_xyd, int cap, int *n, int *node_idx);
+
 /* the frame % balance_period == 5 re-balance that pfslam_step performs first (kernel.cu:1707-1711), as its own
  * entry for callers that drive the stages themselves; pfslam_kd_size = number of map nodes (kdSize) */
 int pfslam_maybe_balance(pfslam_handle *h, int frame);

@@ -1064,6 +1064,92 @@ void orc_update_map_grid(int8_t *grid, int dimx, int dimy, const orc_patch *patc
 }
 
 /* ------------------------------------------------------------------ */
+/* Topology graph + loop-closure proposal (kernel.cu:623-795)           */
+/* ------------------------------------------------------------------ */
+#define ORC_MAX_NODE_DIST 2.5f        /* kernel.cu:34 */
+#define ORC_WALL_CONFIDENCE 30        /* kernel.cu:36 */
+#define ORC_MIN_WALL_COUNT 2          /* kernel.cu:37 */
+#define ORC_CLOSURE_MAP_DIST 6.0f     /* kernel.cu:38 */
+#define ORC_CLOSURE_GRAPH_DIST 20.0f  /* kernel.cu:39 */
+
+static float orc_dist2d(const float a[2], const float b[2])
+{ /* glm::distance(vec2, vec2) = sqrt(dx*dx + dy*dy) */
+    float dx = b[0] - a[0], dy = b[1] - a[1];
+    return sqrtf(dx * dx + dy * dy);
+}
+
+void orc_topology_init(orc_topology *t) /* particleFilterInit, kernel.cu:147-157 */
+{
+    memset(t, 0, sizeof(*t));
+    t->n_nodes = 1;
+    t->node_idx = 0;
+}
+
+static void orc_create_node(orc_topology *t, const float robot[3]) /* CreateNode, kernel.cu:623-648 */
+{
+    if (t->n_nodes >= ORC_TOPO_MAX_NODES) return;
+    float pos[2] = {robot[0], robot[1]};
+    float edgeLen = orc_dist2d(pos, t->pos[t->node_idx]);
+    for (int j = 0; j < t->n_nodes; j++) t->dist[j] += edgeLen;
+    int k = t->n_nodes++;
+    t->pos[k][0] = pos[0];
+    t->pos[k][1] = pos[1];
+    t->dist[k] = 0.0f;
+    t->n_edges[k] = 0;
+    if (t->n_edges[k] < 8) t->edges[k][t->n_edges[k]++] = t->node_idx;
+    if (t->n_edges[t->node_idx] < 8) t->edges[t->node_idx][t->n_edges[t->node_idx]++] = k;
+    t->node_idx = k;
+}
+
+int orc_topology_update(orc_topology *t, const float robot[3])
+{
+    int newNode = 1;
+    for (int j = 0; j < t->n_nodes; j++) newNode &= (orc_dist2d(robot, t->pos[j]) > ORC_MAX_NODE_DIST);
+    if (newNode) orc_create_node(t, robot);
+    return newNode;
+}
+
+int orc_find_walls(const int8_t *grid, int dimx, int dimy, const orc_patch *patch, const float a[2], const float b[2])
+{
+    int ax = (int)roundf(0.5f * dimx + a[0] / patch->res_x + patch->res_x / 2);
+    int ay = (int)roundf(0.5f * dimy + a[1] / patch->res_y + patch->res_y / 2);
+    int bx = (int)roundf(0.5f * dimx + b[0] / patch->res_x + patch->res_x / 2);
+    int by = (int)roundf(0.5f * dimy + b[1] / patch->res_y + patch->res_y / 2);
+    size_t M = (size_t)dimx * dimy;
+    uint8_t *mask = (uint8_t *)calloc(M, 1);
+    orc_trace_ray(ax, ay, bx, by, dimx, dimy, mask);
+    int n = 0; /* CheckVisibility (kernel.cu:651-659); its += is racy in the reference, counted exactly here */
+    for (size_t i = 0; i < M; i++)
+        if (mask[i]) n += (grid[i] > ORC_WALL_CONFIDENCE) ? 1 : 0;
+    free(mask);
+    return n;
+}
+
+int orc_check_loop_closure(const orc_topology *t, const int8_t *grid, int dimx, int dimy, const orc_patch *patch,
+                           const float robot[3], int32_t *pairs, int cap)
+{
+    int n = 0;
+    for (int j = 0; j < t->n_nodes; j++) {
+        if (orc_dist2d(robot, t->pos[j]) < ORC_CLOSURE_MAP_DIST) {
+            float edgeLen = orc_dist2d(robot, t->pos[t->node_idx]);
+            if (edgeLen + t->dist[j] > ORC_CLOSURE_GRAPH_DIST) {
+                for (int k = 0; k < t->n_nodes; k++) {
+                    int nWalls = orc_find_walls(grid, dimx, dimy, patch, robot, t->pos[k]);
+                    if (nWalls < ORC_MIN_WALL_COUNT) {
+                        if (n < cap) {
+                            pairs[2 * n] = j;
+                            pairs[2 * n + 1] = k;
+                        }
+                        n++;
+                    }
+                }
+            }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
 /* Whole step: particleFilter (kernel.cu:1702-1762), KD path            */
 /* ------------------------------------------------------------------ */
 struct orc_slam {

@@ -130,6 +130,24 @@ void orc_score_grid(const int8_t *grid, int dimx, int dimy, const orc_patch *pat
 void orc_update_map_grid(int8_t *grid, int dimx, int dimy, const orc_patch *patch,
                          const float robot[3], const float *scan, int n_beams);
 
+/* ---- topology graph / loop-closure proposal (kernel.cu:623-795; commented out of the shipped step at 1750-1751) ---- */
+#define ORC_TOPO_MAX_NODES 4096
+typedef struct {
+    int n_nodes, node_idx;               /* clusters[0].nodes.size(), clusters[0].nodeIdx */
+    float pos[ORC_TOPO_MAX_NODES][2];    /* Node.pos  */
+    float dist[ORC_TOPO_MAX_NODES];      /* Node.dist */
+    int n_edges[ORC_TOPO_MAX_NODES];
+    int edges[ORC_TOPO_MAX_NODES][8];
+} orc_topology;
+void orc_topology_init(orc_topology *t);
+/* UpdateTopology (kernel.cu:695-726): returns 1 if a node was created */
+int orc_topology_update(orc_topology *t, const float robot[3]);
+/* FindWalls (kernel.cu:661-693) between two world points on the 2-D grid: cells on the Bresenham ray with map > 30 */
+int orc_find_walls(const int8_t *grid, int dimx, int dimy, const orc_patch *patch, const float a[2], const float b[2]);
+/* CheckLoopClosure (kernel.cu:738-795): pairs (closure node j, visible node k); returns the number of pairs written */
+int orc_check_loop_closure(const orc_topology *t, const int8_t *grid, int dimx, int dimy, const orc_patch *patch,
+                           const float robot[3], int32_t *pairs, int cap);
+
 /* ---- whole SLAM step (kernel.cu:1702-1762), KD / point-cloud path ---- */
 typedef struct orc_slam orc_slam;
 typedef struct {

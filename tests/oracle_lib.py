@@ -91,6 +91,10 @@ def lib():
     L.orc_weighted_sample_indices.argtypes = [vp, i32, f32, i32, i32, i32, vp]
     L.orc_score_grid.restype = None; L.orc_score_grid.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, vp]
     L.orc_update_map_grid.restype = None; L.orc_update_map_grid.argtypes = [vp, i32, i32, vp, vp, vp, i32]
+    L.orc_topology_init.restype = None; L.orc_topology_init.argtypes = [vp]
+    L.orc_topology_update.restype = i32; L.orc_topology_update.argtypes = [vp, vp]
+    L.orc_find_walls.restype = i32; L.orc_find_walls.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.orc_check_loop_closure.restype = i32; L.orc_check_loop_closure.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32]
     L.orc_slam_create.restype = vp; L.orc_slam_create.argtypes = [vp]
     L.orc_slam_destroy.restype = None; L.orc_slam_destroy.argtypes = [vp]
     L.orc_slam_set_map.restype = None; L.orc_slam_set_map.argtypes = [vp, vp, i32]
@@ -173,6 +177,38 @@ def get_walls(scan, cx, cy, theta, dimx=1600, dimy=1600, res=0.025):
     fm = np.zeros(dimx * dimy, np.uint8); wm = np.zeros(dimx * dimy, np.uint8)
     lib().orc_get_walls(P(scan), len(scan), cx, cy, float(theta), P(fm), P(wm), dimx, dimy, res, res)
     return fm, wm
+
+
+TOPO_MAX = 4096
+
+
+class Topology(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("node_idx", C.c_int), ("pos", (C.c_float * 2) * TOPO_MAX),
+                ("dist", C.c_float * TOPO_MAX), ("n_edges", C.c_int * TOPO_MAX), ("edges", (C.c_int * 8) * TOPO_MAX)]
+
+    def __init__(self):
+        super().__init__()
+        lib().orc_topology_init(C.byref(self))
+
+    def update(self, robot):
+        r = np.ascontiguousarray(robot, np.float32)
+        return lib().orc_topology_update(C.byref(self), P(r))
+
+    def nodes(self):
+        return np.array([[self.pos[k][0], self.pos[k][1], self.dist[k]] for k in range(self.n_nodes)], np.float32)
+
+    def loop_closure(self, grid, robot, cap=4096):
+        r = np.ascontiguousarray(robot, np.float32)
+        pairs = np.zeros((cap, 2), np.int32)
+        patch = default_patch()
+        n = lib().orc_check_loop_closure(C.byref(self), P(grid), grid.shape[0], grid.shape[1], C.byref(patch), P(r), P(pairs), cap)
+        return pairs[:min(n, cap)].copy()
+
+
+def find_walls(grid, a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    patch = default_patch()
+    return lib().orc_find_walls(P(grid), grid.shape[0], grid.shape[1], C.byref(patch), P(a), P(b))
 
 
 class Slam:

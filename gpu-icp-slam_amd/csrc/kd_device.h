@@ -98,6 +98,14 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
     for (;;) {
         while (head >= 0) { // greedy descent
             const uint4 nd = t.hot[head];
+#ifdef PF_EXP_EXTRA_VALU /* bound-ness experiment: 10 extra dependent VALU per visit, kept alive through sGuard */
+            {
+                float e = __uint_as_float(nd.x);
+#pragma unroll
+                for (int k = 0; k < 10; k++) e = e * 1.0000001f + 1e-30f;
+                if (e == 12345.678f) sGuard = 0.0f;
+            }
+#endif
 #ifdef PF_EXP_EXTRA_LOAD /* bound-ness experiment: a second 16-byte gather per visit, kept alive through sGuard's NaN-ness */
             const uint4 nd2 = t.hot[head ^ 1];
             if (nd2.x == 0x7fc12345u) sGuard = 0.0f;

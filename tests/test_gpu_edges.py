@@ -118,3 +118,43 @@ def test_3d_queries_on_a_planar_map(pkg, small_world):
     want, _ = O.traverse_batch(tree, q)
     assert (h.traverse(q) == want).all()
     h.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_maps_scans_particles(pkg, seed):
+    """Random small worlds: degenerate maps (collinear points, heavy duplicates, tiny trees), random poses far outside the
+    map, random scans.  Traversal and score must equal the oracle bit for bit with integer weights; with arbitrary float
+    weights the beam-chunked sum is deterministic and within 1e-5 relative of the reference's sequential sum."""
+    rng = np.random.RandomState(100 + seed)
+    kind = seed % 3
+    n_pts = int(rng.choice([1, 2, 3, 7, 64, 500, 3000]))
+    pts = np.zeros((n_pts, 4), np.float32)
+    if kind == 0:      # collinear
+        pts[:, 0] = rng.randint(-700, 700, n_pts).astype(np.float32) * np.float32(0.025)
+    elif kind == 1:    # few distinct values, many duplicates
+        pts[:, 0] = rng.randint(-5, 5, n_pts).astype(np.float32) * np.float32(0.025)
+        pts[:, 1] = rng.randint(-5, 5, n_pts).astype(np.float32) * np.float32(0.025)
+    else:              # generic, not grid-snapped
+        pts[:, :2] = rng.uniform(-20, 20, (n_pts, 2))
+    pts[:, 3] = rng.randint(-113, 114, n_pts)
+    tree = pkg.kd_create(pts)
+    assert tree.tobytes() == O.kd_create(pts).tobytes()
+    q = np.zeros((3000, 3), np.float32)
+    q[:, :2] = rng.uniform(-30, 30, (3000, 2))
+    n = int(rng.choice([1, 65, 700]))
+    p = O.make_particles(n)
+    p["x"], p["y"], p["theta"] = rng.uniform(-25, 25, n), rng.uniform(-25, 25, n), rng.uniform(-7, 7, n)
+    scan = rng.uniform(0, 25, 1081).astype(np.float32)
+    h = pkg.PfSlam(n, kd_capacity=max(8, n_pts))
+    h.set_map(tree); h.set_particles(p); h.set_scan(scan)
+    want_idx, _ = O.traverse_batch(tree, q)
+    assert (h.traverse(q) == want_idx).all()
+    assert (bits(h.score_kd()) == bits(O.score_kd(tree, p, scan))).all()
+    # arbitrary float weights
+    t2 = tree.copy()
+    t2["w"] = rng.uniform(-113, 113, n_pts).astype(np.float32)
+    h.set_map(t2)
+    got, want = h.score_kd(), O.score_kd(t2, p, scan)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-3)
+    assert (bits(h.score_kd()) == bits(got)).all()   # deterministic
+    h.close()

@@ -240,6 +240,30 @@ __device__ __forceinline__ bool kd_after_descent_planar(const KdView &t, KdQuery
     return false; // an empty far side (head < 0) ends at the next after-descent test (best unchanged)
 }
 
+// the descent loop of kd_nearest_ref<true> on its own (batched kernel): from q.head until it runs off the tree
+__device__ __forceinline__ void kd_descend_planar(const KdView &t, KdQuery &q)
+{
+    while (q.head >= 0) {
+        const uint4 nd = t.hot[q.head];
+        const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+        const float dx = nx - q.px, dy = ny - q.py;
+        const float s = dx * dx + dy * dy;
+        bool take = s < q.sGuard;
+        const bool inBand = (s < q.sBest) != take;
+        if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
+            float sb = q.sBest;
+            asm volatile("" : "+v"(sb));
+            take = take | (inBand && fsqrt(s) < fsqrt(sb));
+        }
+        q.sBest = take ? s : q.sBest;
+        q.sGuard = take ? s * PF_GUARD_K : q.sGuard;
+        q.bestIdx = take ? q.head : q.bestIdx;
+        const uint32_t axis = nd.z >> 30;
+        const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
+        q.head = (pa < na) ? hot_left(nd.z) : (int)nd.w;
+    }
+}
+
 __device__ __forceinline__ void kd_nearest_ref_x2(const KdView &t, KdQuery &a, KdQuery &b, bool doneA, bool doneB)
 {
     a.sBest = a.sGuard = b.sBest = b.sGuard = INFINITY;

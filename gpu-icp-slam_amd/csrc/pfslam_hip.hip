@@ -206,6 +206,80 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
 }
 
+// Batched variant (variant 5): the sibling re-descents of PF_BATCH consecutive beams are worked off together.  A wave
+// spends about half of its loop trips in the re-descent rounds of a query, where only the lanes whose parent-hyperplane
+// test passed are active (~1/3); here every lane first runs the greedy descents of PF_BATCH beams (well-utilised), parks
+// the four states in LDS, and then walks through ITS OWN pending after-descent tests and re-descents, so a lane that is
+// done with one beam continues with the next instead of idling until the slowest lane of the wave finishes that beam.
+#define PF_BATCH 4
+__global__ __launch_bounds__(256) void k_score_kd_batched(const float *__restrict__ px, const float *__restrict__ py,
+                                                          const float *__restrict__ pth, int n,
+                                                          const float *__restrict__ scan, int nb, int beams_per_chunk,
+                                                          pf::KdView tree, const int *__restrict__ order, int direct,
+                                                          float *__restrict__ out)
+{
+    __shared__ float4 s_task[PF_BATCH][256]; // {px, py, sBest, bestIdx bits}; bestIdx < 0: beam rejected
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * beams_per_chunk;
+    const int j1 = min(nb, j0 + beams_per_chunk);
+    if (slot >= n) return; // no block-level barrier is used: every lane only touches its own LDS column
+    const int i = order ? order[slot] : slot;
+    const float x = px[i], y = py[i], th = pth[i];
+    float acc = 0.0f;
+    for (int jb = j0; jb < j1; jb += PF_BATCH) {
+        const int cnt = min(PF_BATCH, j1 - jb);
+        // phase 1: greedy descents from the root
+        for (int g = 0; g < cnt; g++) {
+            float wx, wy;
+            pf::clean_lidar_scan(jb + g, scan[jb + g], th, wx, wy);
+            pf::KdQuery q;
+            q.px = wx + x;
+            q.py = wy + y;
+            q.sBest = q.sGuard = INFINITY;
+            q.bestIdx = 0;
+            q.prevBest = -1;
+            const bool valid = fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE;
+            q.head = valid ? 0 : -1;
+            pf::kd_descend_planar(tree, q);
+            s_task[g][threadIdx.x] = make_float4(q.px, q.py, q.sBest, __int_as_float(valid ? q.bestIdx : -1));
+        }
+        // phase 2: per lane, in beam order: after-descent test, re-descent, ... until the beam is finished
+        int cur = 0;
+        pf::KdQuery q;
+        q.head = -1;
+        bool loaded = false;
+        for (;;) {
+            // settle tests until this lane has a re-descent to do or has no beam left
+            while (cur < cnt && q.head < 0) {
+                if (!loaded) {
+                    const float4 tk = s_task[cur][threadIdx.x];
+                    q.px = tk.x; q.py = tk.y; q.sBest = tk.z;
+                    q.sGuard = tk.z * PF_GUARD_K;
+                    q.bestIdx = __float_as_int(tk.w);
+                    q.prevBest = -1;
+                    loaded = true;
+                    if (q.bestIdx < 0) { // rejected beam contributes nothing
+                        cur++;
+                        loaded = false;
+                        continue;
+                    }
+                }
+                if (pf::kd_after_descent_planar(tree, q)) {
+                    acc += tree.w[q.bestIdx]; // beam order per lane is preserved
+                    cur++;
+                    loaded = false;
+                    q.head = -1;
+                }
+                // else: q.head is the far child (possibly < 0: an empty side; the next test then ends the beam)
+                else if (q.head < 0) continue;
+            }
+            if (__builtin_amdgcn_ballot_w64(cur < cnt) == 0ull) break;
+            pf::kd_descend_planar(tree, q); // lanes without work have head < 0
+        }
+    }
+    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
+}
+
 // ILP-2 variant: each lane interleaves the traversals of two consecutive beams (planar maps).
 __global__ __launch_bounds__(256) void k_score_kd_x2(const float *__restrict__ px, const float *__restrict__ py,
                                                      const float *__restrict__ pth, int n,
@@ -840,6 +914,9 @@ static int launch_score(pfslam_handle *h)
     if (use_lds)
         hipLaunchKernelGGL(k_score_kd_lds, dim3((h->n + 1023) / 1024, used), dim3(1024), 0, h->stream, h->x, h->y, h->th, h->n,
                            h->scan, h->nb, bpc, kd_view(h), h->top_pos, h->top_orig, h->top_exit, h->top_levels, order, direct, out);
+    else if (h->planar && h->variant == 5)
+        hipLaunchKernelGGL(k_score_kd_batched, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                           kd_view(h), order, direct, out);
     else if (h->planar && h->variant == 4)
         hipLaunchKernelGGL(k_score_kd_x2, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
                            kd_view(h), order, direct, out);

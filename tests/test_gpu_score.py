@@ -167,7 +167,7 @@ def test_score_at_full_bench_size_properties(gpu):
     h.close()
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 def test_score_kernel_variants_are_bit_identical(gpu, small_world, variant):
     """variant 1 = identity lane order, 3 = Morton order + LDS-staged tree top (also after leaf inserts, which touch
     the exit table below the staged levels)."""

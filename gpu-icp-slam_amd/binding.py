@@ -24,7 +24,7 @@ SYMBOLS = [
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
     "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_debug_census",
 ]
 
 
@@ -115,6 +115,7 @@ def load():
     L.pfslam_find_walls.argtypes = [vp, vp, vp, vp]
     L.pfslam_check_loop_closure.argtypes = [vp, vp, i32, vp]
     L.pfslam_get_topology.argtypes = [vp, vp, i32, vp, vp]
+    L.pfslam_debug_census.argtypes = [vp, vp, i32]
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -310,6 +311,11 @@ class PfSlam:
         n, idx = C.c_int(), C.c_int()
         _chk(self.L.pfslam_get_topology(self._h, _p(nodes), cap, C.byref(n), C.byref(idx)), "pfslam_get_topology")
         return nodes[:n.value].copy(), idx.value
+
+    def debug_census(self, reset=True):
+        out = (C.c_ulonglong * 4)()
+        _chk(self.L.pfslam_debug_census(self._h, out, int(reset)), "pfslam_debug_census")
+        return [int(v) for v in out]
 
     def resample_plan(self, frame):
         did, neff = C.c_int(), C.c_float()

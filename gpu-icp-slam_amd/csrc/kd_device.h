@@ -11,6 +11,10 @@
 
 namespace pf {
 
+#ifdef PF_EXP_COUNT /* experiment: loop-trip / active-lane census of the traversal */
+__device__ unsigned long long g_trip_census[4]; // [0] wave trips in the descent loop, [1] active lanes summed, [2] parent tests (wave), [3] lanes in them
+#endif
+
 struct KdView {
     const uint4 *hot;   // {x bits, y bits, left (30-bit two's complement) | axis<<30, right}
     const float *z;     // node z; for a PLANAR map (all z == 0): the true left child of z-level nodes, as int bits
@@ -68,9 +72,10 @@ template <bool PLANAR, bool USE_TOP = false>
 __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, const KdTop top = KdTop{})
 {
     // bestDist starts as the distance to the root; visiting the root first reproduces that state
-    float sBest = INFINITY, sGuard = INFINITY;
+    float sBest = INFINITY;
     int bestIdx = 0, prevBest = -1, head = 0;
     if (USE_TOP) {
+        float sGuard = INFINITY;
         // Phase 1: the staged levels.  Every lane is at the same level, so the split axis is wave-uniform, there is
         // no loop divergence, and a step costs one ds_read_b64 instead of a 16-byte gather through the L1.
         int slot = 0, bestSlot = 0;
@@ -97,18 +102,27 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
     }
     for (;;) {
         while (head >= 0) { // greedy descent
+#ifdef PF_EXP_COUNT
+            {
+                const unsigned long long ex = __builtin_amdgcn_read_exec();
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+                    atomicAdd(&g_trip_census[0], 1ull);
+                    atomicAdd(&g_trip_census[1], (unsigned long long)__popcll(ex));
+                }
+            }
+#endif
             const uint4 nd = t.hot[head];
-#ifdef PF_EXP_EXTRA_VALU /* bound-ness experiment: 10 extra dependent VALU per visit, kept alive through sGuard */
+#ifdef PF_EXP_EXTRA_VALU /* bound-ness experiment: 10 extra dependent VALU per visit, kept alive through sBest */
             {
                 float e = __uint_as_float(nd.x);
 #pragma unroll
                 for (int k = 0; k < 10; k++) e = e * 1.0000001f + 1e-30f;
-                if (e == 12345.678f) sGuard = 0.0f;
+                if (e == 12345.678f) sBest = 0.0f;
             }
 #endif
-#ifdef PF_EXP_EXTRA_LOAD /* bound-ness experiment: a second 16-byte gather per visit, kept alive through sGuard's NaN-ness */
+#ifdef PF_EXP_EXTRA_LOAD /* bound-ness experiment: a second 16-byte gather per visit, kept alive through sBest */
             const uint4 nd2 = t.hot[head ^ 1];
-            if (nd2.x == 0x7fc12345u) sGuard = 0.0f;
+            if (nd2.x == 0x7fc12345u) sBest = 0.0f;
 #endif
             const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
             const float dx = nx - px, dy = ny - py;
@@ -127,6 +141,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             // halves relative gaps); only inside the band -- ~1e-6 of visits -- are the two roots compared.
             // (The relative bound needs normal floats: it assumes two DISTINCT map points are never both within
             // 1e-15 m of a query, i.e. squared distances below 1e-30 occur only for exact coincidence, s == 0.)
+            const float sGuard = sBest * PF_GUARD_K; // recomputed per visit: one multiply instead of a multiply + a select
             bool take = s < sGuard;
             const bool inBand = (s < sBest) != take; // sGuard < sBest, so this is "sGuard <= s < sBest"
             if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) { // wave-uniform, almost never taken
@@ -135,7 +150,6 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
                 take = take | (inBand && fsqrt(s) < fsqrt(sb));
             }
             sBest = take ? s : sBest;
-            sGuard = take ? s * PF_GUARD_K : sGuard;
             bestIdx = take ? head : bestIdx;
             const uint32_t axis = nd.z >> 30;
             float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;
@@ -150,6 +164,15 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         }
         // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
         if (bestIdx == prevBest) break;
+#ifdef PF_EXP_COUNT
+        {
+            const unsigned long long ex = __builtin_amdgcn_read_exec();
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+                atomicAdd(&g_trip_census[2], 1ull);
+                atomicAdd(&g_trip_census[3], (unsigned long long)__popcll(ex));
+            }
+        }
+#endif
         prevBest = bestIdx;
         const float bestDist = fsqrt(sBest);
         const int pi = t.parent[bestIdx];

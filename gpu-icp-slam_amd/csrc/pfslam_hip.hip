@@ -1014,6 +1014,22 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
     return 0;
 }
 
+// experiment support: loop-trip census of the traversal (all zeros unless built with -DPF_EXP_COUNT)
+extern "C" int pfslam_debug_census(pfslam_handle *h, unsigned long long out[4], int reset)
+{
+    if (!h || !out) return fail("pfslam_debug_census: bad argument");
+    memset(out, 0, 32);
+#ifdef PF_EXP_COUNT
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_trip_census), 32));
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pf::g_trip_census), z, 32));
+    }
+#endif
+    return 0;
+}
+
 extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes)
 {
     if (!h || !ptr || !bytes) return fail("pfslam_device_ptr: bad argument");

@@ -168,6 +168,10 @@ int pfslam_set_variant(pfslam_handle *h, int variant);
  * which: 0 sincos (out: n x {sin, cos}), 1 erfcinv, 2 asin, 3 rsqrt, 4 sqrt_rn, 5 x / 0.025f ---- */
 int pfslam_debug_math(pfslam_handle *h, int which, const float *in_host, int n, float *out_host);
 
+/* experiment support: [wave trips of the descent loop, active lanes summed over them, wave-level parent tests, lanes in
+ * them] since the last reset; all zero unless the library is built with -DPF_EXP_COUNT */
+int pfslam_debug_census(pfslam_handle *h, unsigned long long out[4], int reset);
+
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
 int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);
 int pfslam_kd_insert_node(const float p[4], pfslam_node *list, int list_size);

@@ -13,6 +13,8 @@
  *   - RNG (minstd_rand / uniform_real / normal via erfcinv): PINNED against the
  *     image's rocThrust headers compiled for the host (oracle/_ref/thrust_probe);
  *     thrust itself is a dependency absent from /root/reference (CUDA 7.5 toolkit).
+ *   - 3x3 SVD (svd3.h): PINNED on the GPU box against the reference's own svd3.h compiled unmodified for
+ *     the device (oracle/svd_ref_kernel.cpp -> oracle/_ref/svd_ref.hsaco); tests/test_gpu_svd_ref.py.
  *   - Everything that only the CUDA device could execute (traversal, scoring,
  *     ICP kernels, map update, resample): PARITY UNPINNED -- the reference has no
  *     tests / golden vectors and cannot be built or run here (nvcc, libmat, PCL,

@@ -100,6 +100,52 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         bestIdx = top.orig[bestSlot];
         head = top.exit[slot - ((1 << top.levels) - 1)];
     }
+#ifdef PF_FIRST_DESCENT_SPECIAL
+    if (PLANAR && !USE_TOP) {
+        // First descent from the root: every lane of the wave is at the same depth in every trip, and the split axis
+        // of a node is depth % 3, so the three trips of an x / y / z round need no per-node axis decode (and a planar
+        // z-level simply continues right).  Lanes that run off the tree skip the remaining steps; the wave leaves the
+        // round-robin together, which keeps the survivors in phase.  Re-descents start at arbitrary depths and use the
+        // generic loop below.
+        for (;;) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                if (head >= 0) {
+#ifdef PF_EXP_COUNT
+                    {
+                        const unsigned long long ex = __builtin_amdgcn_read_exec();
+                        if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+                            atomicAdd(&g_trip_census[0], 1ull);
+                            atomicAdd(&g_trip_census[1], (unsigned long long)__popcll(ex));
+                        }
+                    }
+#endif
+                    const uint4 nd = t.hot[head];
+                    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+                    const float dx = nx - px, dy = ny - py;
+                    const float s = dx * dx + dy * dy;
+                    const float sGuard = sBest * PF_GUARD_K;
+                    bool take = s < sGuard;
+                    const bool inBand = (s < sBest) != take;
+                    if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
+                        float sb = sBest;
+                        asm volatile("" : "+v"(sb));
+                        take = take | (inBand && fsqrt(s) < fsqrt(sb));
+                    }
+                    sBest = take ? s : sBest;
+                    bestIdx = take ? head : bestIdx;
+                    if (ax == 0)
+                        head = (px < nx) ? hot_left(nd.z) : (int)nd.w;
+                    else if (ax == 1)
+                        head = (py < ny) ? hot_left(nd.z) : (int)nd.w;
+                    else
+                        head = (int)nd.w;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(head >= 0) == 0ull) break;
+        }
+    }
+#endif
     for (;;) {
         while (head >= 0) { // greedy descent
 #ifdef PF_EXP_COUNT

@@ -46,9 +46,9 @@ def _worker(rank, world, port, n_global, n_frames, strict, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("strict", [1, 0])
-def test_two_ranks_match_unsharded_oracle(tmp_path, pkg, oracle, strict):
-    n_global, n_frames, world = 600, 9, 2
+@pytest.mark.parametrize("strict,world", [(1, 2), (0, 2), (1, 4)])
+def test_ranks_match_unsharded_oracle(tmp_path, pkg, oracle, strict, world):
+    n_global, n_frames = 600, 9
     mp.spawn(_worker, args=(world, _free_port(), n_global, n_frames, strict, str(tmp_path)), nprocs=world, join=True)
     o = oracle.Slam(n_global, kd_capacity=1 << 16, strict_host_mirror=strict)
     segs, frames = pkg.synth.corridor_sequence(n_frames, seed=5)

@@ -367,7 +367,12 @@ __device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta
     const float PI_F = 3.1415926535897932384626422832795028841971f; // utilities.h:12
     float rot = fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f) + theta;
     float s, c;
+#ifdef PF_EXP_FAST_TRIG /* experiment: cost share of the fp64 sincos specification (results are NOT bit-exact) */
+    s = __sinf(rot);
+    c = __cosf(rot);
+#else
     sincosf_spec(rot, s, c);
+#endif
     x = range * c;
     y = range * s;
 }

@@ -73,12 +73,12 @@ def load():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.stale():
-        try:
+    try:
+        if _build.stale():
             _build.build()
-        except Exception as e:  # a prebuilt .so that travelled with the snapshot is still usable
-            if not os.path.exists(path):
-                raise PfSlamError("libpfslam_hip.so is missing and could not be built: %s" % e)
+    except Exception as e:  # a prebuilt .so that travelled with the snapshot is still usable
+        if not os.path.exists(path):
+            raise PfSlamError("libpfslam_hip.so is missing and could not be built: %s" % e)
     _one_hip_runtime()
     L = C.CDLL(path)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float

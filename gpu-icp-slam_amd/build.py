@@ -1,4 +1,6 @@
 """Build recipe for libpfslam_hip.so (hipcc, gfx950 only, in-tree so the .so travels with gpurun)."""
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -25,41 +27,63 @@ def hipcc():
     raise RuntimeError("hipcc not found: libpfslam_hip.so cannot be built (there is no CPU fallback)")
 
 
-def _mtime(path):
-    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+def _digest(files):
+    """Content hash of sources + flags: staleness must not depend on file mtimes (the tree is copied between machines)."""
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
-def _unit_stale(src, deps, obj):
-    t = _mtime(obj)
-    return t == 0.0 or any(_mtime(os.path.join(CSRC, f)) > t for f in [src] + deps)
+def _unit_digest(src, deps):
+    return _digest([src] + deps)
+
+
+def _read(path):
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
 
 
 def stale():
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(_mtime(os.path.join(CSRC, f)) > t for src, deps in UNITS.items() for f in [src] + deps)
+    return _read(os.path.join(OBJ, "lib.stamp")) != _digest(sorted({f for s, d in UNITS.items() for f in [s] + d}))
 
 
 def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
     os.makedirs(OBJ, exist_ok=True)
-    cc = hipcc()
-    objs = []
-    for src, deps in UNITS.items():
-        obj = os.path.join(OBJ, src + ".o")
-        objs.append(obj)
-        if force or _unit_stale(src, deps, obj):
-            cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    # one builder at a time: the ranks of a torchrun job import the package concurrently
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not stale():
+            return LIB
+        cc = hipcc()
+        objs = []
+        for src, deps in UNITS.items():
+            obj = os.path.join(OBJ, src + ".o")
+            stamp = obj + ".stamp"
+            objs.append(obj)
+            want = _unit_digest(src, deps)
+            if force or not os.path.exists(obj) or _read(stamp) != want:
+                cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                with open(stamp, "w") as fh:
+                    fh.write(want)
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)  # atomic: a concurrent loader never sees a half-written library
+        with open(os.path.join(OBJ, "lib.stamp"), "w") as fh:
+            fh.write(_digest(sorted({f for s, d in UNITS.items() for f in [s] + d})))
+        return LIB
 
 
 if __name__ == "__main__":

@@ -469,21 +469,12 @@ static int dalloc(T **p, size_t count)
 
 static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw, h->planar}; }
 
-extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
+extern "C" int pfslam_destroy(pfslam_handle *h);
+
+// allocations and initial state of a handle; on failure the caller destroys the partially built handle
+static int create_impl(pfslam_handle *h)
 {
-    if (!cfg || !out) return fail("pfslam_create: null argument");
-    if (cfg->n_particles <= 0 || cfg->n_beams <= 0 || cfg->kd_capacity <= 0)
-        return fail("pfslam_create: n_particles, n_beams and kd_capacity must be positive");
-    if (cfg->n_particles > (1 << 24)) return fail("pfslam_create: at most 2^24 particles per handle");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0)
-        return fail(std::string("pfslam_create: no HIP device available (") + hipGetErrorString(e) +
-                    "); this library has no CPU fallback");
-    if (cfg->device < 0 || cfg->device >= ndev) return fail("pfslam_create: bad device ordinal");
-    HIPCHK(hipSetDevice(cfg->device));
-    pfslam_handle *h = new pfslam_handle();
-    h->cfg = *cfg;
+    const pfslam_config *cfg = &h->cfg;
     h->n = cfg->n_particles;
     h->nb = cfg->n_beams;
     h->gn = cfg->global_n > 0 ? cfg->global_n : cfg->n_particles;
@@ -553,6 +544,31 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     HIPCHK(hipMemsetAsync(h->grid, 0x9c /* -100 */, M, h->stream));
     HIPCHK(hipMemsetAsync(h->stats, 0, 64, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
+{
+    if (!cfg || !out) return fail("pfslam_create: null argument");
+    if (cfg->n_particles <= 0 || cfg->n_beams <= 0 || cfg->kd_capacity <= 0)
+        return fail("pfslam_create: n_particles, n_beams and kd_capacity must be positive");
+    if (cfg->n_particles > (1 << 24)) return fail("pfslam_create: at most 2^24 particles per handle");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(std::string("pfslam_create: no HIP device available (") + hipGetErrorString(e) +
+                    "); this library has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("pfslam_create: bad device ordinal");
+    HIPCHK(hipSetDevice(cfg->device));
+    pfslam_handle *h = new pfslam_handle();
+    h->cfg = *cfg;
+    const int rc = create_impl(h);
+    if (rc) { // release whatever was allocated before the failure; g_err keeps the message of the failure
+        const std::string msg = g_err;
+        pfslam_destroy(h);
+        g_err = msg;
+        return rc;
+    }
     *out = h;
     return 0;
 }

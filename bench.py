@@ -155,6 +155,7 @@ def main():
         from importlib import import_module
         sharded = import_module("gpu-icp-slam_amd.sharded")
         eng = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=a.map_points + (1 << 17), dist=dist, torch=torch)
+        eng.want_best = False
     else:
         eng = pkg.PfSlam(n_local, kd_capacity=a.map_points + (1 << 17), device=local_rank)
     eng.set_map(tree)

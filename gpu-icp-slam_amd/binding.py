@@ -256,7 +256,10 @@ class PfSlam:
     def measurement_local(self):
         _chk(self.L.pfslam_measurement_local(self._h), "pfslam_measurement_local")
 
-    def measurement_apply(self):
+    def measurement_apply(self, fetch=True):
+        if not fetch:  # no read-back, no host synchronisation
+            _chk(self.L.pfslam_measurement_apply(self._h, None, None, None), "pfslam_measurement_apply")
+            return None
         best, fmin, fmax = C.c_int(), C.c_float(), C.c_float()
         _chk(self.L.pfslam_measurement_apply(self._h, C.byref(best), C.byref(fmin), C.byref(fmax)),
              "pfslam_measurement_apply")

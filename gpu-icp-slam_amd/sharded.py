@@ -61,6 +61,7 @@ class ShardedSlam:
             buffers = GpuBuffers(engine, torch, device)
         self.eng, self.buf = engine, buffers
         self._last = {}
+        self.want_best = True  # trace()['best'] costs one tiny read-back per step; bench.py turns it off
 
     # -- pass-throughs
     def set_map(self, tree): self.eng.set_map(tree)
@@ -73,10 +74,12 @@ class ShardedSlam:
     @property
     def pose(self): return self.eng.pose
 
-    def _all_gather(self, dst, src):
+    def _all_gather(self, dst, src, async_op=False):
+        """Returns a work handle when async_op (wait() it before the result is used), else None."""
         if self.world == 1:
             dst.copy_(src)
-        else:
+            return None
+        return self.dist.all_gather_into_tensor(dst, src, async_op=async_op) if async_op else \
             self.dist.all_gather_into_tensor(dst, src)
 
     def step(self, frame, scan):
@@ -93,16 +96,20 @@ class ShardedSlam:
         e.measurement_local()
         if self.world > 1:
             d.all_reduce(b.stats[:2], op=d.ReduceOp.MAX)
-        best, fmin, fmax = e.measurement_apply()
+        e.measurement_apply(fetch=False)             # weights + this rank's share of the best pose; no host sync
         if self.world > 1:
             d.all_reduce(b.start, op=d.ReduceOp.SUM)
+        # the weights are final after measurement_apply: gather them while ICP and the map update (replicated) run
+        pending = self._all_gather(b.gw, b.w, async_op=True)
         e.icp(None)
-        self._all_gather(b.gw, b.w)
         e.update_map_kd()
+        if pending is not None:
+            pending.wait()
         did, neff = e.resample_plan(frame)
         if did:
             local, glob = b.pose_views()
             for dst, src in zip(glob, local):
                 self._all_gather(dst, src)
             e.resample_gather()
+        best = int(0xFFFFFFFF - (int(b.stats[0].item()) & 0xFFFFFFFF)) if self.want_best else -1
         self._last = {"best": best, "resampled": did, "neff": neff, "kd_size": e.kd_size}

@@ -123,7 +123,7 @@ class OracleShardEngine:
         self.stats[0] = np.max((f32_to_ordered(self.fit) << 32) | (0xFFFFFFFF - gi))
         self.stats[1] = np.max(f32_to_ordered(-self.fit) << 32)
 
-    def measurement_apply(self):
+    def measurement_apply(self, fetch=True):
         fmax = ordered_to_f32(self.stats[0] >> 32)
         fmin = -ordered_to_f32(self.stats[1] >> 32)
         best = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF))

@@ -249,3 +249,26 @@ def test_step_replay_matches_oracle(gpu, n, strict):
         assert (bits(got[fld]) == bits(want[fld])).all(), fld
     assert any(True for _ in frames)
     h.close(); o.close()
+
+
+def test_long_replay_across_two_rebalances(gpu):
+    """110 frames: the KDTree::Balance of frame 5 and of frame 105 (with ~100 frames of leaf inserts in between),
+    many resamples, H11 weight reverts -- every frame's trace and pose, and the final tree / particles, bit-identical."""
+    n = 96
+    segs, frames = gpu.synth.corridor_sequence(110, seed=9, n_points=2500)
+    o = O.Slam(n, kd_capacity=1 << 17)
+    h = gpu.PfSlam(n, kd_capacity=1 << 17)
+    resampled = 0
+    for f, (pose, scan) in enumerate(frames, start=1):
+        o.step(f, scan)
+        h.step(f, scan)
+        to, tg = o.trace(), h.trace()
+        assert tg == to, (f, tg, to)
+        assert (bits(h.pose) == bits(o.pose)).all(), f
+        resampled += to["resampled"]
+    assert resampled >= 5 and o.kd_size > 3000
+    assert h.map().tobytes() == o.tree().tobytes()
+    got, want = h.particles(), o.particles()
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[fld]) == bits(want[fld])).all(), fld
+    h.close(); o.close()

@@ -3,6 +3,7 @@
 // kernel.h:42-60); everything else is a thin forwarding layer onto include/pfslam.h.
 #include "kernel.h"
 #include "pointcloud.h"
+#include "mat5_reader.h"
 #include "../../include/pfslam.h"
 
 #include <cmath>
@@ -44,6 +45,15 @@ static bool next_line(std::ifstream &f, std::string &line)
 Lidar::Lidar(std::string filename)
 {
     std::cout << "Reading lidar data from " << filename << " ..." << std::endl;
+    const bool is_mat = filename.size() > 4 && filename.compare(filename.size() - 4, 4, ".mat") == 0;
+    if (is_mat) { // the reference's format: MAT-v5, cell array `lidar` of structs with a `scan` field (lidar.cpp:17-49)
+        std::string err;
+        if (!mat5_read_lidar_scans(filename, scans, err)) {
+            std::cout << "Error reading from file - aborting! (" << err << ")" << std::endl;
+            throw std::runtime_error("Lidar: " + err);
+        }
+        return;
+    }
     std::ifstream f(filename, std::ios::binary);
     if (!f.is_open()) {
         std::cout << "Error reading from file - aborting!" << std::endl;
@@ -53,7 +63,7 @@ Lidar::Lidar(std::string filename)
     const std::streamoff bytes = f.tellg();
     f.seekg(0);
     const int beams = 1081;
-    if (bytes % (beams * 4) != 0) throw std::runtime_error("Lidar: file is not frames x 1081 float32 (convert .mat with tools/mat2bin.py)");
+    if (bytes % (beams * 4) != 0) throw std::runtime_error("Lidar: file is neither .mat nor frames x 1081 float32");
     const size_t frames = (size_t)(bytes / (beams * 4));
     scans.resize(frames, std::vector<float>(beams));
     for (size_t i = 0; i < frames; i++) f.read(reinterpret_cast<char *>(scans[i].data()), beams * 4);

@@ -1,6 +1,7 @@
 """The C++ host layer (gpu-icp-slam_amd/host: kernel.h / Lidar / Scene / Pointcloud / KDTree drop-ins)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -68,3 +69,32 @@ def test_replay_binary_matches_python_step(tmp_path, pkg):
         assert got == h.pose.view(np.uint32).tolist(), line
         assert int(tok[-1]) == h.trace()["kd_size"] and int(tok[-3]) == 300
     h.close()
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_lidar_reads_the_reference_mat_format(tmp_path, pkg, compress):
+    """The reference's input files are MATLAB v5: cell array `lidar`, each cell a struct with a single[1081] field `scan`
+    (src/lidar.cpp:17-49, via libmat).  host/mat5_reader.cpp reads them natively, compressed or not."""
+    sio = pytest.importorskip("scipy.io")
+    build_host(pkg)
+    rng = np.random.RandomState(3)
+    scans = rng.uniform(0.1, 30, (7, 1081)).astype(np.float32)
+    cells = np.empty((1, 7), dtype=object)
+    for i in range(7):
+        rec = {"t": float(i) * 0.025, "scan": scans[i].reshape(1, -1), "pose": np.zeros((3, 1))}
+        if i == 4:
+            del rec["scan"]          # a cell without `scan` is skipped by the reference (pScan == NULL)
+        cells[0, i] = rec
+    mat = tmp_path / "train_lidar_test.mat"
+    sio.savemat(str(mat), {"other": np.arange(5.0), "lidar": cells}, do_compression=compress)
+    scene = tmp_path / "scene.txt"
+    scene.write_text(SCENE_TXT)
+    cloud = tmp_path / "cloud.txt"
+    cloud.write_text("1 2 3\n4 5 6\n")
+    out = subprocess.check_output([os.path.join(HOST, "pfslam_host_selftest"), str(scene), str(mat), str(cloud)]).decode()
+    assert "lidar 6 1081 %.6f %.6f" % (scans[0, 0], scans[6, -1]) in out
+    # the converter in tools/ agrees
+    conv = tmp_path / "conv.f32"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mat2bin.py"), str(mat), str(conv)], stdout=subprocess.DEVNULL)
+    got = np.fromfile(str(conv), np.float32).reshape(-1, 1081)
+    assert (got == np.delete(scans, 4, axis=0)).all()

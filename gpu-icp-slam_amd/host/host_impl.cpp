@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 
@@ -35,7 +36,7 @@ static std::vector<std::string> tokens_of(const std::string &line)
     while (ss >> t) out.push_back(t);
     return out;
 }
-static bool next_line(std::ifstream &f, std::string &line)
+static bool next_line(std::istream &f, std::string &line)
 {
     if (!std::getline(f, line)) { line.clear(); return false; }
     if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -72,25 +73,25 @@ Lidar::Lidar(std::string filename)
 Scene::Scene(std::string filename)
 {
     std::cout << "Reading scene from " << filename << " ..." << std::endl;
-    fp_in.open(filename);
-    if (!fp_in.is_open()) {
+    std::ifstream in(filename);
+    if (!in.is_open()) {
         std::cout << "Error reading from file - aborting!" << std::endl;
         throw std::runtime_error("Scene: cannot open " + filename);
     }
     std::string line;
-    while (next_line(fp_in, line)) {
+    while (next_line(in, line)) {
         const auto t = tokens_of(line);
         if (t.empty()) continue;
-        if (t[0] == "MAP") loadGeom();
-        else if (t[0] == "CAMERA") loadCamera();
+        if (t[0] == "MAP") parse_map_block(in);
+        else if (t[0] == "CAMERA") parse_camera_block(in);
     }
 }
-int Scene::loadGeom()
+void Scene::parse_map_block(std::istream &in)
 {
     glm::vec3 gridSize;
     float res = 1.0f;
     std::string line;
-    while (next_line(fp_in, line) && !line.empty()) {
+    while (next_line(in, line) && !line.empty()) {
         const auto t = tokens_of(line);
         if (t.empty()) break;
         if (t[0] == "SIZE" && t.size() >= 3) gridSize = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), 0);
@@ -102,13 +103,12 @@ int Scene::loadGeom()
     m.grid = nullptr;
     m.uid = 0;
     maps.push_back(m);
-    return 1;
 }
-int Scene::loadCamera()
+void Scene::parse_camera_block(std::istream &in)
 {
     Camera &c = state.camera;
     std::string line;
-    while (next_line(fp_in, line) && !line.empty()) {
+    while (next_line(in, line) && !line.empty()) {
         const auto t = tokens_of(line);
         if (t.empty()) break;
         if (t[0] == "RES" && t.size() >= 3) c.resolution = glm::ivec2(atoi(t[1].c_str()), atoi(t[2].c_str()));
@@ -118,7 +118,6 @@ int Scene::loadCamera()
         else if (t[0] == "LOOKAT" && t.size() >= 4) c.lookAt = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
         else if (t[0] == "UP" && t.size() >= 4) c.up = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
     }
-    return 1;
 }
 
 Pointcloud::Pointcloud(std::string filename)

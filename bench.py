@@ -110,6 +110,26 @@ def extras(pkg, O, tree, pts, scan, device):
         ex["grid_path_10k_particles"] = {"gpu_evals_per_s": n / dt, "ms_per_call_incl_minmax_weights": dt * 1e3,
                                          "cpu_oracle_1thread_evals_per_s": 2048 / tc, "parity_sample_ok": bool((fit[:256] == want).all())}
         h.close()
+        # whole 2-D frame loop (BASELINE configs[1]: 10 k particles) and configs[0]'s 50 particles, on a short drive
+        _, frames = pkg.synth.corridor_sequence(30, seed=5)
+        for nn, key in ((10000, "grid_step_10k_particles"), (50, "grid_step_50_particles")):
+            h = pkg.PfSlam(nn, device=device)
+            for f in range(1, 11):
+                h.step_grid(f, frames[f - 1][1])
+            h.synchronize()
+            t0 = time.perf_counter()
+            for f in range(11, 31):
+                h.step_grid(f, frames[f - 1][1])
+            h.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            ex[key] = {"ms_per_frame": dt * 1e3, "evals_per_s": nn / dt}
+            h.close()
+        o = O.Slam(50)
+        t0 = time.perf_counter()
+        for f in range(1, 31):
+            o.step_grid(f, frames[f - 1][1])
+        ex["grid_step_50_particles"]["cpu_oracle_1thread_ms_per_frame"] = (time.perf_counter() - t0) / 30 * 1e3
+        o.close()
     except Exception as e:  # extras must never break the contract line
         ex["error"] = repr(e)
     return ex

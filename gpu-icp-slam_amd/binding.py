@@ -17,7 +17,7 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
@@ -90,6 +90,7 @@ def load():
     L.pfslam_set_stream.argtypes = [vp, vp]
     L.pfslam_synchronize.argtypes = [vp]
     L.pfslam_step.argtypes = [vp, i32, vp]
+    L.pfslam_step_grid.argtypes = [vp, i32, vp]
     L.pfslam_get_pose.argtypes = [vp, vp]
     L.pfslam_get_particles.argtypes = [vp, vp, vp]
     L.pfslam_get_map.argtypes = [vp, vp, vp]
@@ -339,6 +340,11 @@ class PfSlam:
     def step(self, frame, scan):
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         _chk(self.L.pfslam_step(self._h, frame, _p(scan)), "pfslam_step")
+
+    def step_grid(self, frame, scan):
+        """One frame of the 2-D occupancy-grid variant (motion, grid score + weights, grid update, resample)."""
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        _chk(self.L.pfslam_step_grid(self._h, frame, _p(scan)), "pfslam_step_grid")
 
     def traverse(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

@@ -135,6 +135,7 @@ Pointcloud::Pointcloud(std::string filename)
 
 // ---------------------------------------------------------------- kernel.h
 static pfslam_handle *g_handle = nullptr;
+static bool g_grid_map = false;
 static Scene *g_scene = nullptr;
 static int g_particles = 1000; // PARTICLE_COUNT, kernel.cu:30
 static glm::vec3 g_robotPos;
@@ -153,6 +154,7 @@ void particleFilterInit(Scene *scene)
 {
     g_scene = scene;
     if (const char *e = getenv("PFSLAM_PARTICLES")) pfslamSetParticleCount(atoi(e));
+    if (const char *e = getenv("PFSLAM_MAP")) g_grid_map = strcmp(e, "grid") == 0;
     pfslam_config cfg;
     pfslam_default_config(&cfg);
     cfg.n_particles = g_particles;
@@ -182,8 +184,12 @@ void particleFilter(uchar4 *, int frame, Lidar *lidar)
         fprintf(stderr, "particleFilter: not initialised or frame out of range\n");
         exit(EXIT_FAILURE);
     }
-    PFCHK(pfslam_step(g_handle, frame, lidar->scans[frame].data()), "particleFilter");
+    if (g_grid_map)
+        PFCHK(pfslam_step_grid(g_handle, frame, lidar->scans[frame].data()), "particleFilter (grid)");
+    else
+        PFCHK(pfslam_step(g_handle, frame, lidar->scans[frame].data()), "particleFilter");
 }
+void pfslamUseGridMap(bool on) { g_grid_map = on; }
 void drawMap(uchar4 *) {}
 
 void getPCData(Particle **ptrParticles, MAP_TYPE **ptrMap, KDTree::Node **ptrKD, int *nParticles, int *nKD, glm::vec3 &pos)

@@ -22,6 +22,10 @@ void particleFilterFreePC();
 // PARTICLE_COUNT is a compile-time 1000 in the reference (kernel.cu:30); here it is a runtime setting read by the
 // next particleFilterInit (also: environment variable PFSLAM_PARTICLES).
 void pfslamSetParticleCount(int n);
+// The reference keeps both map representations in the source and wires the point-cloud one (kernel.cu:1730-1745);
+// this selects which stages particleFilter() runs: false = KD point cloud (default), true = 2-D occupancy grid
+// (PFMeasurementUpdate / PFUpdateMap).  Also: environment variable PFSLAM_MAP=grid.
+void pfslamUseGridMap(bool on);
 
 // error convention of the reference: print and exit (kernel.h:42-60)
 void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line);

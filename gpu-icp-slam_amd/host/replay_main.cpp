@@ -1,5 +1,5 @@
 // replay_main.cpp -- headless counterpart of the reference's main loop (main.cpp:47-96, 175-229):
-//   pfslam_replay <scene.txt> <lidar.f32> [frames]
+//   pfslam_replay <scene.txt> <lidar.f32|.mat> [frames] [grid]      ("grid": the 2-D occupancy-grid stages)
 // iteration 0: Free + Init; then particleFilter(pbo=NULL, ++iteration, lidar) until the scans run out.
 // Prints one line per frame (pose, map size) and the mean step time.
 #include <chrono>
@@ -11,13 +11,14 @@
 int main(int argc, char **argv)
 {
     if (argc < 3) {
-        printf("Usage: %s SCENEFILE.txt LIDARFILE.f32 [frames]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt LIDARFILE.f32|.mat [frames] [grid]\n", argv[0]);
         return 1;
     }
     Scene *scene = new Scene(argv[1]);
     Lidar *lidar = new Lidar(argv[2]);
     size_t last = lidar->scans.size() - 1;
-    if (argc > 3) last = std::min(last, (size_t)atoi(argv[3]));
+    if (argc > 3 && atoi(argv[3]) > 0) last = std::min(last, (size_t)atoi(argv[3]));
+    if (argc > 4 && strcmp(argv[4], "grid") == 0) pfslamUseGridMap(true);
     particleFilterFree();
     particleFilterInit(scene);
     double total_ms = 0;

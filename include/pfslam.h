@@ -80,6 +80,10 @@ int pfslam_synchronize(pfslam_handle *h);
 
 /* ---- whole step (kernel.h:16) ---- */
 int pfslam_step(pfslam_handle *h, int frame, const float *scan_host);
+/* The same frame loop with the reference's 2-D occupancy-grid stages (PFMotionUpdate kernel.cu:400-418,
+ * PFMeasurementUpdate 307-339, PFUpdateMap 551-577, PFResample 447-511): pose = best particle, grid updated
+ * in place.  The grid starts at -100 everywhere (kernel.cu:124) unless pfslam_set_grid replaced it. */
+int pfslam_step_grid(pfslam_handle *h, int frame, const float *scan_host);
 
 /* ---- read-back (kernel.h:19): non-owning pointers into the handle's host mirrors, valid until the next call */
 int pfslam_get_pose(pfslam_handle *h, float pose[3]);

@@ -1167,6 +1167,8 @@ struct orc_slam {
     uint8_t *create;
     int32_t trace[8];
     int n_wall, n_free;
+    int8_t *grid;   /* occupancyGrid, kernel.cu:122-124 (allocated on first grid use) */
+    int32_t *fit_i; /* dev_fit */
 };
 
 orc_slam *orc_slam_create(const orc_slam_config *cfg)
@@ -1203,6 +1205,7 @@ void orc_slam_destroy(orc_slam *s)
     if (!s) return;
     free(s->dev); free(s->host); free(s->kd); free(s->fit); free(s->free_mask); free(s->wall_mask);
     free(s->wall_pts); free(s->free_pts); free(s->wall_c); free(s->free_c); free(s->create);
+    free(s->grid); free(s->fit_i);
     free(s);
 }
 
@@ -1308,6 +1311,71 @@ void orc_slam_step(orc_slam *s, int frame, const float *scan)
     s->trace[6] = s->kd_size;
 }
 
+/* 2-D occupancy-grid variant of the step.  The reference defines the four stages (PFMotionUpdate 400-418,
+ * PFMeasurementUpdate 307-339 GPU branch, PFUpdateMap 551-577 GPU branch, PFResample 447-511) but its shipped
+ * particleFilter() calls the KD versions; this is the same frame loop with the 2-D stages in their places
+ * (SURVEY 3.3).  Every frame runs all four stages: there is no first-frame special case because the grid
+ * starts at -100 everywhere (kernel.cu:124), which scores every particle equally. */
+static void orc_slam_grid_alloc(orc_slam *s)
+{
+    if (s->grid) return;
+    size_t M = (size_t)s->dimx * s->dimy;
+    s->grid = (int8_t *)malloc(M);
+    memset(s->grid, -100, M);
+    s->fit_i = (int32_t *)calloc((size_t)s->cfg.n_particles, sizeof(int32_t));
+}
+void orc_slam_set_grid(orc_slam *s, const int8_t *grid)
+{
+    orc_slam_grid_alloc(s);
+    memcpy(s->grid, grid, (size_t)s->dimx * s->dimy);
+}
+const int8_t *orc_slam_grid(orc_slam *s)
+{
+    orc_slam_grid_alloc(s);
+    return s->grid;
+}
+void orc_slam_step_grid(orc_slam *s, int frame, const float *scan)
+{
+    int n = s->cfg.n_particles;
+    orc_slam_grid_alloc(s);
+    memset(s->trace, 0, sizeof(s->trace));
+    /* PFMotionUpdate */
+    memcpy(s->dev, s->host, sizeof(orc_particle) * (size_t)n);
+    orc_add_noise(s->dev, n, frame, 0);
+    memcpy(s->host, s->dev, sizeof(orc_particle) * (size_t)n);
+    /* PFMeasurementUpdate, GPU branch (kernel.cu:309-339) */
+    orc_score_grid(s->grid, s->dimx, s->dimy, &s->cfg.patch, s->dev, n, scan, s->cfg.n_beams, s->fit_i);
+    int imin, imax;
+    orc_minmax_first_i32(s->fit_i, n, &imin, &imax);
+    int rng = s->fit_i[imax] - s->fit_i[imin];
+    int best = imax;
+    if (rng > 0) {
+        float f = 1 / (float)rng;
+        orc_update_weights_i32(s->dev, n, s->fit_i, f, s->fit_i[imin]);
+    }
+    if (s->cfg.strict_host_mirror)
+        memcpy(s->host, s->dev, (size_t)n * 16); /* same half-array copy as the KD path (kernel.cu:337) */
+    else
+        memcpy(s->host, s->dev, sizeof(orc_particle) * (size_t)n);
+    s->robot[0] = s->host[best].x;
+    s->robot[1] = s->host[best].y;
+    s->robot[2] = s->host[best].theta;
+    s->trace[0] = best;
+    /* PFUpdateMap, GPU branch */
+    orc_update_map_grid(s->grid, s->dimx, s->dimy, &s->cfg.patch, s->robot, scan, s->cfg.n_beams);
+    /* PFResample */
+    float neff;
+    int did = orc_resample(s->dev, n, frame, &neff, 0);
+    if (did) memcpy(s->host, s->dev, sizeof(orc_particle) * (size_t)n);
+    s->trace[1] = did;
+    memcpy(&s->trace[5], &neff, 4);
+}
+
+void orc_slam_set_particles(orc_slam *s, const orc_particle *p)
+{
+    memcpy(s->dev, p, sizeof(orc_particle) * (size_t)s->cfg.n_particles);
+    memcpy(s->host, p, sizeof(orc_particle) * (size_t)s->cfg.n_particles);
+}
 void orc_slam_get_pose(const orc_slam *s, float pose[3]) { memcpy(pose, s->robot, 12); }
 int orc_slam_kd_size(const orc_slam *s) { return s->kd_size; }
 const orc_node *orc_slam_tree(const orc_slam *s) { return s->kd; }

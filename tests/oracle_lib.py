@@ -99,6 +99,10 @@ def lib():
     L.orc_slam_destroy.restype = None; L.orc_slam_destroy.argtypes = [vp]
     L.orc_slam_set_map.restype = None; L.orc_slam_set_map.argtypes = [vp, vp, i32]
     L.orc_slam_step.restype = None; L.orc_slam_step.argtypes = [vp, i32, vp]
+    L.orc_slam_step_grid.restype = None; L.orc_slam_step_grid.argtypes = [vp, i32, vp]
+    L.orc_slam_set_grid.restype = None; L.orc_slam_set_grid.argtypes = [vp, vp]
+    L.orc_slam_grid.restype = vp; L.orc_slam_grid.argtypes = [vp]
+    L.orc_slam_set_particles.restype = None; L.orc_slam_set_particles.argtypes = [vp, vp]
     L.orc_slam_get_pose.restype = None; L.orc_slam_get_pose.argtypes = [vp, vp]
     L.orc_slam_kd_size.restype = i32; L.orc_slam_kd_size.argtypes = [vp]
     L.orc_slam_tree.restype = vp; L.orc_slam_tree.argtypes = [vp]
@@ -237,6 +241,26 @@ class Slam:
     def step(self, frame, scan):
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         lib().orc_slam_step(self.h, frame, P(scan))
+
+    def set_particles(self, p):
+        assert len(p) == self.n
+        lib().orc_slam_set_particles(self.h, P(np.ascontiguousarray(p)))
+
+    def step_grid(self, frame, scan):
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        lib().orc_slam_step_grid(self.h, frame, P(scan))
+
+    def set_grid(self, grid):
+        grid = np.ascontiguousarray(grid, dtype=np.int8)
+        lib().orc_slam_set_grid(self.h, P(grid))
+
+    @property
+    def grid(self):
+        ptr = lib().orc_slam_grid(self.h)
+        p = self.cfg.patch
+        dimx, dimy = int(np.float32(p.scale_x) / np.float32(p.res_x)), int(np.float32(p.scale_y) / np.float32(p.res_y))
+        buf = (C.c_char * (dimx * dimy)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.int8).reshape(dimx, dimy).copy()
 
     @property
     def pose(self):

@@ -69,6 +69,16 @@ def test_replay_binary_matches_python_step(tmp_path, pkg):
         assert got == h.pose.view(np.uint32).tolist(), line
         assert int(tok[-1]) == h.trace()["kd_size"] and int(tok[-3]) == 300
     h.close()
+    # the 2-D occupancy-grid stages behind the same particleFilter() entry point
+    out = subprocess.check_output([os.path.join(HOST, "pfslam_replay"), str(scene), str(lidar), "0", "grid"], env=env).decode()
+    lines = [l for l in out.splitlines() if l.startswith("frame ")]
+    assert len(lines) == len(frames)
+    h = pkg.PfSlam(300, kd_capacity=1 << 16)
+    for f, ((pose, scan), line) in enumerate(zip(frames, lines), start=1):
+        h.step_grid(f, scan)
+        tok = line.split()
+        assert [int(tok[k], 16) for k in (7, 8, 9)] == h.pose.view(np.uint32).tolist(), line
+    h.close()
 
 
 @pytest.mark.parametrize("compress", [False, True])

@@ -17,7 +17,7 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_debug_graph_probe", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",

@@ -175,6 +175,9 @@ int pfslam_debug_math(pfslam_handle *h, int which, const float *in_host, int n, 
 /* experiment support: [wave trips of the descent loop, active lanes summed over them, wave-level parent tests, lanes in
  * them] since the last reset; all zero unless the library is built with -DPF_EXP_COUNT */
 int pfslam_debug_census(pfslam_handle *h, unsigned long long out[4], int reset);
+/* experiment hook: the launch-bound chain of pfslam_step_grid as plain launches vs a captured hipGraph;
+ * out_ms[0] = direct, out_ms[1] = graph replay, per chain (tools/graph_probe.py) */
+int pfslam_debug_graph_probe(pfslam_handle *h, int iters, float out_ms[2]);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
 int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);

@@ -157,7 +157,23 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
                 }
             }
 #endif
+#ifdef PF_EXP_UNIFORM_SLOAD /* experiment: when the whole wave stands on one node, fetch it through the scalar cache */
+            uint4 nd;
+            {
+                const int uh = __builtin_amdgcn_readfirstlane(head);
+                if (__builtin_amdgcn_ballot_w64(head != uh) == 0ull) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 r;
+                    const uint4 *p = t.hot + uh;
+                    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+                    nd.x = r.x; nd.y = r.y; nd.z = r.z; nd.w = r.w;
+                } else {
+                    nd = t.hot[head];
+                }
+            }
+#else
             const uint4 nd = t.hot[head];
+#endif
 #ifdef PF_EXP_EXTRA_VALU /* bound-ness experiment: 10 extra dependent VALU per visit, kept alive through sBest */
             {
                 float e = __uint_as_float(nd.x);

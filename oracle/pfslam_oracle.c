@@ -1276,7 +1276,12 @@ void orc_slam_step(orc_slam *s, int frame, const float *scan)
         orc_add_noise(s->dev, n, frame, 0);
         memcpy(s->host, s->dev, sizeof(orc_particle) * (size_t)n);
         /* PFMeasurementUpdateKD (kernel.cu:1311-1348) */
-        orc_score_kd(s->kd, s->dev, n, scan, s->cfg.n_beams, s->fit, 0, 0);
+        {   /* ORC_THREADS=k: particles scored on k threads (same per-particle arithmetic; soak tests on the GPU box) */
+            const char *e = getenv("ORC_THREADS");
+            int nt = e ? atoi(e) : 1;
+            if (nt > 1) orc_score_kd_mt(s->kd, s->dev, n, scan, s->cfg.n_beams, s->fit, nt);
+            else orc_score_kd(s->kd, s->dev, n, scan, s->cfg.n_beams, s->fit, 0, 0);
+        }
         int imin, imax;
         orc_minmax_first_f32(s->fit, n, &imin, &imax);
         float rng = s->fit[imax] - s->fit[imin];

@@ -272,3 +272,30 @@ def test_long_replay_across_two_rebalances(gpu):
     for fld in ("x", "y", "theta", "w"):
         assert (bits(got[fld]) == bits(want[fld])).all(), fld
     h.close(); o.close()
+
+
+@pytest.mark.parametrize("n,nframes", [(20000, 60), (100000, 24)])
+def test_soak_replay_at_scale(gpu, monkeypatch, n, nframes):
+    """Longer, larger replays than the stage tests: 20 000 particles x 60 frames and BASELINE configs[2]'s 100 000
+    particles x 24 frames (balance at frame 5, many resamples, H5 seed collisions at N > 1024, H11 reverts) -- every
+    frame's trace and pose and the final tree / particles bit-identical.  The oracle scores on the host's cores
+    (ORC_THREADS; per-particle arithmetic is unchanged)."""
+    import os
+    monkeypatch.setenv("ORC_THREADS", str(min(128, os.cpu_count() or 1)))
+    segs, frames = gpu.synth.corridor_sequence(nframes, seed=21, n_points=6000)
+    o = O.Slam(n, kd_capacity=1 << 17)
+    h = gpu.PfSlam(n, kd_capacity=1 << 17)
+    resampled = 0
+    for f, (pose, scan) in enumerate(frames, start=1):
+        o.step(f, scan)
+        h.step(f, scan)
+        to, tg = o.trace(), h.trace()
+        assert tg == to, (f, tg, to)
+        assert (bits(h.pose) == bits(o.pose)).all(), f
+        resampled += to["resampled"]
+    assert resampled >= 5
+    assert h.map().tobytes() == o.tree().tobytes()
+    got, want = h.particles(), o.particles()
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[fld]) == bits(want[fld])).all(), fld
+    h.close(); o.close()

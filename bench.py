@@ -222,8 +222,8 @@ def main():
                        "particles_global": n_global, "parallelism": "particles sharded x%d, map replicated" % world,
                        "kd_size_end": trace.get("kd_size")},
         }
-        # ---- roofline of the dominant kernel + CPU baseline (N = 1 only) -------------------------
-        if world == 1:
+        # ---- roofline of the dominant kernel (rank 0's launches) + CPU baseline and extras (N = 1 only) ----
+        if True:
             import oracle_lib as O
             # the oracle measures V (mean node visits of the reference traversal) and the CPU rate on the map and the
             # particle cloud as they are at the END of the timed region (the map grows where the scan lands)
@@ -231,7 +231,7 @@ def main():
             tree_end = np.ascontiguousarray(e0.map(), dtype=O.NODE_DTYPE)
             p0 = np.ascontiguousarray(e0.particles(), dtype=O.PARTICLE_DTYPE)
             last_scan = scans[n_frames - 1]
-            if a.no_cpu_baseline:
+            if a.no_cpu_baseline or world > 1:
                 _, visits, valid = O.score_kd(tree_end, p0[:128], last_scan, stats=True)
                 vbar, bvalid = visits / max(valid, 1), valid / 128
             else:
@@ -255,7 +255,8 @@ def main():
                                "kernel_evals_per_s": n_local / (kern_ms * 1e-3),
                                "note": "algorithmic node bytes are served from L2/L1 (the 1.6 MB hot tree is cache "
                                        "resident); compulsory HBM traffic is ~20 B/eval, hence frac can exceed 1"}
-            out["extras"] = extras(pkg, O, tree, pts, scans[0], local_rank)
+            if world == 1:
+                out["extras"] = extras(pkg, O, tree, pts, scans[0], local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

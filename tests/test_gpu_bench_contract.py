@@ -28,3 +28,29 @@ def test_bench_json_line_has_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 5000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+def _torchrun(nproc, port, *bench_args):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3",
+           "--warmup", "1", "--particles", "4096", "--map-points", "20000"] + list(bench_args)
+    out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_torchrun_rccl_one_rank():
+    """The driver's launch form; one rank over RCCL exercises the sharded engine and the nccl process group."""
+    d = _torchrun(1, 29551)
+    assert d["n_gpus"] == 1 and d["config"]["particles_global"] == 4096 and d["roofline"]["launches"] == 3
+    assert "cpu_baseline" in d
+
+
+def test_bench_under_torchrun_two_ranks_on_one_gpu():
+    """Two ranks (gloo, both on GPU 0 -- RCCL refuses two ranks per device): whole-job value counts both shards, rank 0
+    prints the only line, and the roofline of rank 0's launches is still there."""
+    d = _torchrun(2, 29552, "--backend", "gloo", "--same-device")
+    assert d["n_gpus"] == 2 and d["config"]["particles_global"] == 8192 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8192 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert d["roofline"]["launches"] == 3 and "cpu_baseline" not in d

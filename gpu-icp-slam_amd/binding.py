@@ -17,7 +17,7 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_debug_graph_probe", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_finish", "pfslam_debug_graph_probe", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
@@ -91,6 +91,8 @@ def load():
     L.pfslam_synchronize.argtypes = [vp]
     L.pfslam_step.argtypes = [vp, i32, vp]
     L.pfslam_step_grid.argtypes = [vp, i32, vp]
+    L.pfslam_shard_begin.argtypes = [vp, i32, vp, vp]
+    L.pfslam_shard_finish.argtypes = [vp, i32, vp, vp]
     L.pfslam_get_pose.argtypes = [vp, vp]
     L.pfslam_get_particles.argtypes = [vp, vp, vp]
     L.pfslam_get_map.argtypes = [vp, vp, vp]
@@ -266,8 +268,12 @@ class PfSlam:
              "pfslam_measurement_apply")
         return best.value, fmin.value, fmax.value
 
-    def icp(self, start=None):
-        """start=None: use the device-resident best-particle pose left by measurement_apply."""
+    def icp(self, start=None, fetch=True):
+        """start=None: use the device-resident best-particle pose left by measurement_apply.
+        fetch=False: launch only (no read-back, no host synchronisation)."""
+        if not fetch:
+            _chk(self.L.pfslam_icp(self._h, None, None, None), "pfslam_icp")
+            return None
         out = np.zeros(3, np.float32)
         dbg = np.zeros(32, np.float32)
         if start is None:
@@ -340,6 +346,18 @@ class PfSlam:
     def step(self, frame, scan):
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         _chk(self.L.pfslam_step(self._h, frame, _p(scan)), "pfslam_step")
+
+    def shard_begin(self, frame, scan):
+        """Sharded frame, first half (see include/pfslam.h); returns True when the frame only seeded the map."""
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        seeded = C.c_int(0)
+        _chk(self.L.pfslam_shard_begin(self._h, frame, _p(scan), C.byref(seeded)), "pfslam_shard_begin")
+        return bool(seeded.value)
+
+    def shard_finish(self, frame):
+        did, neff = C.c_int(0), C.c_float(0)
+        _chk(self.L.pfslam_shard_finish(self._h, frame, C.byref(did), C.byref(neff)), "pfslam_shard_finish")
+        return did.value, neff.value
 
     def step_grid(self, frame, scan):
         """One frame of the 2-D occupancy-grid variant (motion, grid score + weights, grid update, resample)."""

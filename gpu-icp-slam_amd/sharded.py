@@ -83,29 +83,22 @@ class ShardedSlam:
             self.dist.all_gather_into_tensor(dst, src)
 
     def step(self, frame, scan):
+        """One frame; the host synchronises once (in shard_finish), everything else is enqueued."""
         e, d, b = self.eng, self.dist, self.buf
-        e.set_scan(scan)
-        e.maybe_balance(frame)
-        if e.kd_size == 0:                      # first scan seeds the map (kernel.cu:1714-1717); replicated
-            e.set_pose(np.zeros(3, np.float32))
-            e.update_map_kd()
+        if e.shard_begin(frame, scan):          # first scan seeds the map (kernel.cu:1714-1717); replicated
             self._last = {"best": -1, "resampled": 0, "kd_size": e.kd_size}
             return
-        e.motion_update(frame)
-        e.score_kd(fetch=False)
-        e.measurement_local()
         if self.world > 1:
             d.all_reduce(b.stats[:2], op=d.ReduceOp.MAX)
-        e.measurement_apply(fetch=False)             # weights + this rank's share of the best pose; no host sync
+        e.measurement_apply(fetch=False)        # weights + this rank's share of the best pose
         if self.world > 1:
             d.all_reduce(b.start, op=d.ReduceOp.SUM)
-        # the weights are final after measurement_apply: gather them while ICP and the map update (replicated) run
+        # the weights are final after measurement_apply: gather them while the (replicated) ICP runs
         pending = self._all_gather(b.gw, b.w, async_op=True)
-        e.icp(None)
-        e.update_map_kd()
+        e.icp(None, fetch=False)
         if pending is not None:
-            pending.wait()
-        did, neff = e.resample_plan(frame)
+            pending.wait()                      # stream-level: orders the compute stream behind the collective
+        did, neff = e.shard_finish(frame)       # map update, Neff on the global weights, resample plan; the one host sync
         if did:
             local, glob = b.pose_views()
             for dst, src in zip(glob, local):

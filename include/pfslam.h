@@ -150,6 +150,12 @@ int pfslam_kd_size(pfslam_handle *h);
  * rest reserved.  key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index).            */
 int pfslam_measurement_local(pfslam_handle *h);  /* score must have run; fills the stats buffer */
 int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, float *fmax); /* after the all-reduce */
+/* The sharded frame in two calls (one host sync per frame, like pfslam_step); the caller's collectives run between
+ * them on the handle's stream:  shard_begin -> all-reduce MAX of buffer 0 -> pfslam_measurement_apply -> all-reduce SUM
+ * of buffer 8 + all-gather of buffer 5 into buffer 10 -> pfslam_icp -> shard_finish -> if *resampled: all-gather of
+ * buffers 2-4 into 11-13 -> pfslam_resample_gather.  *seeded = 1 when the frame only seeded the map (first scan). */
+int pfslam_shard_begin(pfslam_handle *h, int frame, const float *scan_host, int *seeded);
+int pfslam_shard_finish(pfslam_handle *h, int frame, int *resampled, float *neff);
 /* device pointers of the handle's buffers, for zero-copy wrapping by the harness.
  * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta, 5 w (n x f32 each), 6 weight tile sums,
  *        7 scan (n_beams x f32), 8 best-particle pose (4 x f32), 9 robot pose (4 x f32),

@@ -141,7 +141,25 @@ class OracleShardEngine:
             self.start[:3] = (self.x[lb], self.y[lb], self.th[lb])
         return best, float(fmin), float(fmax)
 
-    def icp(self, start=None):
+    def shard_begin(self, frame, scan):
+        """pfslam_shard_begin: scan, re-balance if due, (first scan: seed the map), dispersion, score, local keys."""
+        self.set_scan(scan)
+        self.maybe_balance(frame)
+        if self.size == 0:
+            self.set_pose(np.zeros(3, np.float32))
+            self.update_map_kd()
+            return True
+        self.motion_update(frame)
+        self.score_kd(fetch=False)
+        self.measurement_local()
+        return False
+
+    def shard_finish(self, frame):
+        """pfslam_shard_finish: map update at the ICP pose, then Neff / resample plan on the gathered weights."""
+        self.update_map_kd()
+        return self.resample_plan(frame)
+
+    def icp(self, start=None, fetch=True):
         s = self.start[:3] if start is None else np.asarray(start, np.float32)
         pose, dbg = O.icp(self.tree, self.robot, s, self.scan)
         self.robot[:] = pose

@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/golden_v1.npz, made by tests/golden/make_golden.py).
+"""Committed golden vectors (tests/golden/golden_v1.npz and golden_v2.npz, made by tests/golden/make_golden*.py).
 CPU part: the oracle still reproduces them and the product's host tree code reproduces the REFERENCE's kdtree.cpp
 output stored in them (no /root/reference needed at test time).  GPU part: the HIP path reproduces them."""
 import ctypes as C
@@ -134,4 +134,64 @@ def test_hip_step_replay_reproduces_golden(pkg):
         assert row == G["replay_trace"][f - 1].tolist(), f
     p = h.particles()
     assert (bits(np.stack([p["x"], p["y"], p["theta"], p["w"]], 1)) == bits(G["replay_particles"])).all()
+    h.close()
+
+
+# ---- golden_v2: the 2-D frame loop and the topology graph (rows added after golden_v1) ----------------------
+def _v2():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2.npz"))
+
+
+def _check_grid_replay(step, trace, pose, grid, particles, G):
+    import zlib
+    scans = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz"))["replay_scans"]
+    for f, scan in enumerate(scans, start=1):
+        step(f, scan)
+        t = trace()
+        row = [t["best"], t["resampled"], int(np.float32(t["neff"]).view(np.int32))] + [int(v) for v in pose().view(np.int32)]
+        assert row == G["grid_replay_trace"][f - 1].tolist(), f
+    g = grid()
+    assert zlib.crc32(g.tobytes()) == int(G["grid_replay_crc"]) and int((g < -100).sum()) == int(G["grid_replay_free_count"])
+    cells = np.flatnonzero(g.ravel() > -100)
+    assert (cells == G["grid_replay_wall_cells"]).all() and (g.ravel()[cells] == G["grid_replay_wall_vals"]).all()
+    p = particles()
+    got = np.stack([p["x"], p["y"], p["theta"], p["w"]], 1)
+    assert (got.view(np.int32) == G["grid_replay_particles"].view(np.int32)).all()
+
+
+def test_oracle_reproduces_golden_v2(oracle):
+    G = _v2()
+    o = O.Slam(200)
+    _check_grid_replay(o.step_grid, o.trace, lambda: o.pose, lambda: o.grid, o.particles, G)
+    o.close()
+    t = O.Topology()
+    created = [t.update(r) for r in G["topo_path"]]
+    assert created == G["topo_created"].tolist() and (t.nodes().view(np.int32) == G["topo_nodes"].view(np.int32)).all()
+    grid = np.full(1600 * 1600, -100, np.int8)
+    grid[G["topo_grid_cells"]] = 113
+    grid = grid.reshape(1600, 1600)
+    assert (t.loop_closure(grid, G["topo_path"][-1]) == G["topo_pairs"]).all() and len(G["topo_pairs"]) > 0
+    assert O.find_walls(grid, G["topo_walls_a"], G["topo_walls_b"]) == int(G["topo_walls_n"]) == 2
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_golden_v2(pkg):
+    assert pkg.device_count() > 0
+    G = _v2()
+    h = pkg.PfSlam(200)
+    _check_grid_replay(h.step_grid, h.trace, lambda: h.pose, h.grid, h.particles, G)
+    grid = np.full(1600 * 1600, -100, np.int8)
+    grid[G["topo_grid_cells"]] = 113
+    h.set_grid(grid.reshape(1600, 1600))
+    created, n_prev = [], 1          # the graph starts with the origin node (particleFilterInit)
+    for r in G["topo_path"]:
+        h.set_pose(r)
+        n = h.topology_update()
+        created.append(n - n_prev)
+        n_prev = n
+    assert created == G["topo_created"].tolist()
+    nodes, node_idx = h.topology()
+    assert (np.asarray(nodes, np.float32).view(np.int32) == G["topo_nodes"].view(np.int32)).all()
+    assert (h.check_loop_closure() == G["topo_pairs"]).all()
+    assert h.find_walls(G["topo_walls_a"], G["topo_walls_b"]) == int(G["topo_walls_n"])
     h.close()

@@ -55,6 +55,31 @@ __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, i
     return r;
 }
 
+// Tree gathers go through buffer descriptors: a 32-bit byte offset (one shift) instead of a sign-extended 64-bit flat
+// address per visit -- measured 2.40 vs 2.46 ms for the score kernel.  The descriptors are wave-uniform (SGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t kd_rsrc_t;
+__device__ __forceinline__ kd_rsrc_t kd_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, /*bytes*/ 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ uint4 kd_load_hot(kd_rsrc_t r, int idx)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, idx << 4, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int kd_load_i32(kd_rsrc_t r, int idx)
+{
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, idx << 2, 0, 0);
+}
+#else // hipcc's host pass only parses the device templates below; the descriptor type does not exist there
+struct kd_rsrc_t { const void *base; };
+__device__ kd_rsrc_t kd_rsrc(const void *base);
+__device__ uint4 kd_load_hot(kd_rsrc_t r, int idx);
+__device__ int kd_load_i32(kd_rsrc_t r, int idx);
+#endif
+
 // The traversal of kernel.cu:881-919 (== 931-969, 1147-1184, 1239-1276): greedy descent, then
 // while the best node changed, one look at the best node's parent hyperplane and a re-descent of
 // the sibling side.  It is NOT an exact nearest-neighbour search and is reproduced as is.
@@ -146,6 +171,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         }
     }
 #endif
+    const kd_rsrc_t hot_rsrc = kd_rsrc(t.hot), parent_rsrc = kd_rsrc(t.parent);
     for (;;) {
         while (head >= 0) { // greedy descent
 #ifdef PF_EXP_COUNT
@@ -157,7 +183,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
                 }
             }
 #endif
-#ifdef PF_EXP_UNIFORM_SLOAD /* experiment: when the whole wave stands on one node, fetch it through the scalar cache */
+#if defined(PF_EXP_UNIFORM_SLOAD) /* experiment: when the whole wave stands on one node, fetch it through the scalar cache */
             uint4 nd;
             {
                 const int uh = __builtin_amdgcn_readfirstlane(head);
@@ -168,11 +194,11 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
                     asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
                     nd.x = r.x; nd.y = r.y; nd.z = r.z; nd.w = r.w;
                 } else {
-                    nd = t.hot[head];
+                    nd = kd_load_hot(hot_rsrc, head);
                 }
             }
 #else
-            const uint4 nd = t.hot[head];
+            const uint4 nd = kd_load_hot(hot_rsrc, head);
 #endif
 #ifdef PF_EXP_EXTRA_VALU /* bound-ness experiment: 10 extra dependent VALU per visit, kept alive through sBest */
             {
@@ -237,9 +263,9 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
 #endif
         prevBest = bestIdx;
         const float bestDist = fsqrt(sBest);
-        const int pi = t.parent[bestIdx];
+        const int pi = kd_load_i32(parent_rsrc, bestIdx);
         if (pi < 0) break; // H1
-        const uint4 nd = t.hot[pi];
+        const uint4 nd = kd_load_hot(hot_rsrc, pi);
         const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
         const uint32_t axis = nd.z >> 30;
         float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;

@@ -212,16 +212,20 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             const uint4 nd2 = t.hot[head ^ 1];
             if (nd2.x == 0x7fc12345u) sBest = 0.0f;
 #endif
-            const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
-            const float dx = nx - px, dy = ny - py;
-            float s = dx * dx + dy * dy;
-            float nz = 0.0f;
+            // (node - query) as a 2-vector: v_pk_add_f32 / v_pk_mul_f32, one rounding per component as in the scalar form
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 nxy = {__uint_as_float(nd.x), __uint_as_float(nd.y)};
+            const f32x2 pxy = {px, py};
+            const f32x2 d = nxy - pxy;
+            const f32x2 dd = d * d;
+            float s = dd.x + dd.y;
+            float dz = 0.0f;
             int zleft = 0; // generic kernel on a planar map (query with z != 0): the z array holds z-level left children
             if (!PLANAR) {
                 const float zraw = t.z[head];
-                nz = t.planar ? 0.0f : zraw;
+                const float nz = t.planar ? 0.0f : zraw;
                 zleft = __float_as_int(zraw);
-                const float dz = nz - pz;
+                dz = nz - pz;
                 s = s + dz * dz;
             }
             // d < bestDist, decided without a sqrt: if s is below sBest by more than a guard band of 2^-21
@@ -239,13 +243,12 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             }
             sBest = take ? s : sBest;
             bestIdx = take ? head : bestIdx;
+            // query < node on the split axis, read off the difference already computed: denormals are kept
+            // (float_denorm_mode 3), so node - query > 0 exactly when query < node (NaN: both false)
             const uint32_t axis = nd.z >> 30;
-            float pa = axis == 0 ? px : py, na = axis == 0 ? nx : ny;
-            if (!PLANAR) {
-                pa = axis == 2 ? pz : pa;
-                na = axis == 2 ? nz : na;
-            }
-            const bool lt = pa < na; // PLANAR z levels: both links hold the right child
+            float da = axis == 0 ? d.x : d.y;
+            if (!PLANAR) da = axis == 2 ? dz : da;
+            const bool lt = da > 0.0f; // PLANAR z levels: both links hold the right child
             int left = hot_left(nd.z);
             if (!PLANAR) left = (t.planar && axis == 2) ? zleft : left;
             head = lt ? left : (int)nd.w;

@@ -253,6 +253,15 @@ def main():
                                "kernel": "k_score_kd", "kernel_ms": kern_ms, "launches": launches,
                                "alg_bytes_per_eval": bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                                "kernel_evals_per_s": n_local / (kern_ms * 1e-3),
+                               # the unit that actually bounds the kernel: one wave-level gather per node
+                               # visit, ~16 TA cycles each per CU.  Lower bound on the gathers: perfectly coherent waves.
+                               "gather_issue": {
+                                   "wave_gathers_per_launch_min": n_local / 64.0 * bvalid * vbar,
+                                   "rate_min_per_s": n_local / 64.0 * bvalid * vbar / (kern_ms * 1e-3),
+                                   "peak_per_s": 256 * 2.4e9 / 16.0,
+                                   "frac_min": n_local / 64.0 * bvalid * vbar / (kern_ms * 1e-3) / (256 * 2.4e9 / 16.0),
+                                   "note": "peak = 256 CUs x 2.4 GHz / 16 cycles per wave gather (tools/ubench/gather_rate.hip); "
+                                           "the PMC count of gathers is ~10 % above this minimum (profiles/r01_pmc_memory_path.json)"},
                                "note": "algorithmic node bytes are served from L2/L1 (the 1.6 MB hot tree is cache "
                                        "resident); compulsory HBM traffic is ~20 B/eval, hence frac can exceed 1"}
             if world == 1:

@@ -985,7 +985,7 @@ void orc_weighted_sample_indices(const float *cdf, int n, float neff, int frame,
 
 int orc_resample(orc_particle *p, int n, int frame, float *neff_out, int32_t *src_idx)
 {
-    float *w = (float *)malloc(sizeof(float) * (size_t)n);
+    float *w = (float *)calloc((size_t)(n > 0 ? n : 1), sizeof(float));
     for (int i = 0; i < n; i++) w[i] = p[i].w * p[i].w; /* kernCopyWeights squared */
     float r2 = orc_sum_f32(w, n, 1);
     for (int i = 0; i < n; i++) w[i] = p[i].w;

@@ -171,11 +171,15 @@ class PfSlam:
     """One handle = one GPU's shard of particles + a replica of the map."""
 
     def __init__(self, n_particles, n_beams=1081, kd_capacity=1 << 20, device=0, strict_host_mirror=1,
-                 free_upload_bug=0, balance_period=100, global_offset=0, global_n=0):
+                 free_upload_bug=0, balance_period=100, global_offset=0, global_n=0, map_scale=None, map_res=None):
         L = load()
         cfg = Config()
         L.pfslam_default_config(C.byref(cfg))
         cfg.n_particles, cfg.n_beams, cfg.kd_capacity, cfg.device = n_particles, n_beams, kd_capacity, device
+        if map_scale is not None:   # (x, y) extent of the map in metres (default 40 x 40, data/map_settings.txt)
+            cfg.map_scale_x, cfg.map_scale_y = map_scale
+        if map_res is not None:     # (x, y) cell size in metres (default 0.025)
+            cfg.map_res_x, cfg.map_res_y = map_res
         cfg.strict_host_mirror, cfg.free_upload_bug, cfg.balance_period = strict_host_mirror, free_upload_bug, balance_period
         cfg.global_offset, cfg.global_n = global_offset, global_n
         self.cfg = cfg

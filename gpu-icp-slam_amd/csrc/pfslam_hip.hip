@@ -554,6 +554,16 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     if (cfg->n_particles <= 0 || cfg->n_beams <= 0 || cfg->kd_capacity <= 0)
         return fail("pfslam_create: n_particles, n_beams and kd_capacity must be positive");
     if (cfg->n_particles > (1 << 24)) return fail("pfslam_create: at most 2^24 particles per handle");
+    if (!(cfg->map_res_x > 0.0f && cfg->map_res_y > 0.0f && cfg->map_scale_x > 0.0f && cfg->map_scale_y > 0.0f))
+        return fail("pfslam_create: map scale and resolution must be positive");
+    {
+        // map_dim = int(scale / resolution) per axis (kernel.cu:120).  The reference addresses cell (x, y) as x * dim.x + y
+        // everywhere, which is only a bijection onto the dim.x * dim.y grid when the map is square (its own map is 40 x 40 m):
+        // a wider map reads out of bounds, a taller one aliases rows.  Refuse instead of guessing a meaning.
+        const int dx = (int)(cfg->map_scale_x / cfg->map_res_x), dy = (int)(cfg->map_scale_y / cfg->map_res_y);
+        if (dx != dy) return fail("pfslam_create: the map must have as many cells in x as in y (reference cell index is x * dim.x + y)");
+        if (dx < 2 || (long long)dx * dy > (1ll << 28)) return fail("pfslam_create: map dimensions out of range");
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

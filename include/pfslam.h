@@ -52,7 +52,9 @@ typedef struct pfslam_config {
     int32_t n_particles;   /* PARTICLE_COUNT (kernel.cu:30), runtime here; particles owned by THIS handle */
     int32_t n_beams;       /* LIDAR_SIZE (kernel.cu:43) = 1081 */
     float map_scale_x, map_scale_y; /* Patch.scale (data/map_settings.txt: 40 40) */
-    float map_res_x, map_res_y;     /* Patch.resolution (0.025) */
+    float map_res_x, map_res_y;     /* Patch.resolution (0.025).  int(scale / res) must be the same in x and y: the
+                                     * reference indexes cell (x, y) as x * dim.x + y (kernel.cu:120, 539, 1438), which is
+                                     * only well defined on a square grid; pfslam_create refuses anything else */
     int32_t kd_capacity;   /* KD_MAX_SIZE (kernel.cu:77); nodes */
     int32_t device;        /* HIP device ordinal */
     int32_t strict_host_mirror; /* 1 = reproduce the half-array weight read-back of kernel.cu:1341 (H11) */

@@ -219,8 +219,8 @@ class Slam:
     """Whole-step oracle (particleFilter, kernel.cu:1702-1762)."""
 
     def __init__(self, n_particles, n_beams=1081, kd_capacity=1 << 20, strict_host_mirror=1,
-                 free_upload_bug=0, balance_period=100):
-        self.cfg = SlamConfig(n_particles, n_beams, default_patch(), kd_capacity, strict_host_mirror,
+                 free_upload_bug=0, balance_period=100, patch=None):
+        self.cfg = SlamConfig(n_particles, n_beams, patch if patch is not None else default_patch(), kd_capacity, strict_host_mirror,
                               free_upload_bug, balance_period)
         self.h = lib().orc_slam_create(C.byref(self.cfg))
         self.n = n_particles

@@ -158,3 +158,32 @@ def test_fuzz_maps_scans_particles(pkg, seed):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-3)
     assert (bits(h.score_kd()) == bits(got)).all()   # deterministic
     h.close()
+
+
+def test_non_default_map_and_beam_count(pkg):
+    """Nothing is hard-wired to 1081 beams / 40 m / 0.025 m: a 30 x 30 m map of 0.05 m cells and 721 beams (-135..+45 deg)
+    replays bit-identically, KD path and 2-D path; a non-square map is refused (the reference's x * dim.x + y cell index)."""
+    import ctypes as C
+    segs, frames = pkg.synth.corridor_sequence(12, seed=7)
+    patch = O.Patch(30.0, 30.0, 0.05, 0.05)
+    kw = dict(n_beams=721, kd_capacity=1 << 16)
+    o = O.Slam(300, patch=patch, **kw)
+    h = pkg.PfSlam(300, map_scale=(30.0, 30.0), map_res=(0.05, 0.05), **kw)
+    for f, (_, scan) in enumerate(frames, start=1):
+        scan = np.ascontiguousarray(scan[:721])
+        o.step(f, scan); h.step(f, scan)
+        assert h.trace() == o.trace(), f
+        assert (h.pose.view(np.int32) == o.pose.view(np.int32)).all()
+        assert (h.cells(0) == o.cells(0)).all() and (h.cells(1) == o.cells(1)).all()
+    assert h.map().tobytes() == o.tree().tobytes() and o.kd_size > 100
+    h.close(); o.close()
+    o = O.Slam(300, patch=patch, **kw)
+    h = pkg.PfSlam(300, map_scale=(30.0, 30.0), map_res=(0.05, 0.05), **kw)
+    for f, (_, scan) in enumerate(frames, start=1):
+        scan = np.ascontiguousarray(scan[:721])
+        o.step_grid(f, scan); h.step_grid(f, scan)
+        assert h.trace() == o.trace(), f
+    assert (h.grid() == o.grid).all() and h.grid().shape == o.grid.shape
+    h.close(); o.close()
+    with pytest.raises(pkg.PfSlamError):
+        pkg.PfSlam(8, map_scale=(40.0, 30.0))

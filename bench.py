@@ -253,8 +253,8 @@ def main():
                                "kernel": "k_score_kd", "kernel_ms": kern_ms, "launches": launches,
                                "alg_bytes_per_eval": bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                                "kernel_evals_per_s": n_local / (kern_ms * 1e-3),
-                               # the unit that actually bounds the kernel: one wave-level gather per node
-                               # visit, ~16 TA cycles each per CU.  Lower bound on the gathers: perfectly coherent waves.
+                               # one of the units that saturate in this kernel: one wave-level gather per
+                               # node visit, ~16 TA cycles each per CU.  Lower bound on the gathers: perfectly coherent waves.
                                "gather_issue": {
                                    "wave_gathers_per_launch_min": n_local / 64.0 * bvalid * vbar,
                                    "rate_min_per_s": n_local / 64.0 * bvalid * vbar / (kern_ms * 1e-3),

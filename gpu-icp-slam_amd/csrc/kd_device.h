@@ -66,7 +66,12 @@ __device__ __forceinline__ kd_rsrc_t kd_rsrc(const void *base)
 __device__ __forceinline__ uint4 kd_load_hot(kd_rsrc_t r, int idx)
 {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifdef PF_EXP_IDXEN /* experiment: structured addressing (descriptor stride 16): the hardware scales the index, no shift */
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 idxen\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(idx), "s"(r) : "memory");
+#else
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, idx << 4, 0, 0);
+#endif
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ int kd_load_i32(kd_rsrc_t r, int idx)
@@ -171,7 +176,12 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         }
     }
 #endif
+#ifdef PF_EXP_IDXEN
+    const kd_rsrc_t hot_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(t.hot), /*stride*/ 16, /*records*/ 0x7ffffff, 0x00020000);
+    const kd_rsrc_t parent_rsrc = kd_rsrc(t.parent);
+#else
     const kd_rsrc_t hot_rsrc = kd_rsrc(t.hot), parent_rsrc = kd_rsrc(t.parent);
+#endif
     for (;;) {
         while (head >= 0) { // greedy descent
 #ifdef PF_EXP_COUNT

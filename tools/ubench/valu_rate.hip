@@ -1,0 +1,91 @@
+// valu_rate.hip -- issue cost of the VALU instructions the traversal uses, gfx950, 8 waves per SIMD, independent chains.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rate tools/ubench/valu_rate.hip && ./valu_rate
+// Prints cycles per wave-instruction per SIMD (kernel cycles / instructions issued on one SIMD).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define REP8(x) x x x x x x x x
+#define BODY(ASM) \
+    for (int it = 0; it < iters; it++) { REP8(REP8(asm volatile(ASM : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)) }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_valu(int iters, float *out)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 1.0000001f, c = 1e-30f;
+    f32x2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a1, a0}, p3 = {a3, a2}, pb = {b, b};
+    unsigned long long m = 0x5555555555555555ull;
+    if (OP == 0) BODY("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5")
+    if (OP == 1) BODY("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4")
+    if (OP == 2) BODY("v_add_f32 %0, %0, %5\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %5")
+    if (OP == 3) BODY("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3")
+    if (OP == 4) BODY("v_bfe_i32 %0, %0, 0, 30\n v_bfe_i32 %1, %1, 0, 30\n v_bfe_i32 %2, %2, 0, 30\n v_bfe_i32 %3, %3, 0, 30")
+    if (OP == 5) BODY("v_cvt_f32_i32 %0, %0\n v_cvt_f32_i32 %1, %1\n v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3")
+    if (OP == 6) {
+        for (int it = 0; it < iters; it++) {
+            REP8(REP8(asm volatile("v_cndmask_b32 %0, %0, %4, %5\n v_cndmask_b32 %1, %1, %4, %5\n v_cndmask_b32 %2, %2, %4, %5\n v_cndmask_b32 %3, %3, %4, %5"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "s"(m));))
+        }
+    }
+    if (OP == 7) {
+        for (int it = 0; it < iters; it++) {
+            REP8(REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cmp_lt_f32 vcc, %1, %4\n v_cmp_lt_f32 vcc, %2, %4\n v_cmp_lt_f32 vcc, %3, %4"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");))
+        }
+    }
+    if (OP == 8) {
+        for (int it = 0; it < iters; it++) {
+            REP8(REP8(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
+                                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));))
+        }
+        a0 = p0.x + p1.y; a1 = p2.x; a2 = p3.y; a3 = 0;
+    }
+    if (OP == 9) {
+        for (int it = 0; it < iters; it++) {
+            REP8(REP8(asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4"
+                                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));))
+        }
+        a0 = p0.x + p1.y; a1 = p2.x; a2 = p3.y; a3 = 0;
+    }
+    if (OP == 10) {
+        for (int it = 0; it < iters; it++) {
+            REP8(REP8(asm volatile("v_cmp_lt_f32 %4, %0, %5\n v_cmp_lt_f32 %4, %1, %5\n v_cmp_lt_f32 %4, %2, %5\n v_cmp_lt_f32 %4, %3, %5"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(m) : "v"(b));))
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(m & 1);
+}
+
+template <int OP>
+static void run(const char *name, float *out, int cus, double ghz)
+{
+    const int blocks = cus * 8, iters = 200; // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    k_valu<OP><<<blocks, 256>>>(10, out);
+    (void)hipEventRecord(a);
+    k_valu<OP><<<blocks, 256>>>(iters, out);
+    (void)hipEventRecord(b);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    const double instr_per_simd = 8.0 * iters * 64 * 4; // 8 waves x iters x 64 asm blocks x 4 instructions
+    printf("%-22s %.3f ms -> %.2f cycles per wave-instruction per SIMD\n", name, ms, ms * 1e-3 * ghz * 1e9 / instr_per_simd);
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    (void)hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    const double ghz = p.clockRate * 1e-6;
+    float *out;
+    (void)hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
+    printf("%d CUs, %.2f GHz nominal\n", cus, ghz);
+    run<0>("v_fma_f32", out, cus, ghz); run<1>("v_mul_f32", out, cus, ghz); run<2>("v_add_f32", out, cus, ghz);
+    run<3>("v_lshlrev_b32", out, cus, ghz); run<4>("v_bfe_i32", out, cus, ghz); run<5>("v_cvt_f32_i32", out, cus, ghz);
+    run<6>("v_cndmask_b32 (sgpr)", out, cus, ghz); run<7>("v_cmp_lt_f32 vcc", out, cus, ghz); run<10>("v_cmp_lt_f32 sgpr", out, cus, ghz);
+    run<8>("v_pk_mul_f32", out, cus, ghz); run<9>("v_pk_add_f32", out, cus, ghz);
+    return 0;
+}

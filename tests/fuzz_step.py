@@ -1,10 +1,10 @@
 """Differential fuzz of the whole frame loop (KD and 2-D variants) against the oracle: random configurations and adversarial
 scans (NaN / Inf / zero / out-of-range beams, robot driven to the map edge, tiny capacity headroom).  Run on the GPU box:
-    python tools/fuzz_step.py [seconds] [seed]
+    python tests/fuzz_step.py [seconds] [seed]
 Exits non-zero at the first divergence and prints the case."""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # this script lives in tests/: it drives the oracle
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import oracle_lib as O
 pkg = importlib.import_module("gpu-icp-slam_amd")

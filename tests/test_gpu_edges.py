@@ -190,10 +190,10 @@ def test_non_default_map_and_beam_count(pkg):
 
 
 def test_differential_fuzz_of_the_frame_loop():
-    """20 s of tools/fuzz_step.py: random particle counts / beam counts / map geometry / parity flags / balance periods,
+    """20 s of tests/fuzz_step.py: random particle counts / beam counts / map geometry / parity flags / balance periods,
     adversarial scans (NaN, Inf, zero, negative, out of range), clouds at the map edge, tiny capacity headroom -- KD and
     2-D frame loops stay bit-identical to the oracle frame by frame."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step.py"), "20", "7"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_step.py"), "20", "7"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -141,6 +141,13 @@ struct pfslam_handle {
     std::vector<float> h_tmp;
     int32_t trace[8] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ICP needs only the scan, the previous pose and the map (kernel.cu:974-1075): it runs on `aux` under the score kernel
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool icp_forked = false;      // aux work in flight (between fork_icp and join_icp)
+    bool icp_delta_ready = false; // joined: icp_dbg[24..27] holds this frame's increment, not yet added to the best particle
+    bool masks_cleared = false;   // the aux stream already zeroed the free / wall masks for this frame
+    bool stats_clean = false;     // ... and reset the min/max keys
     // live timing of the dominant kernel inside pfslam_step (bench.py roofline leg)
     int timing = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_pending;
@@ -487,6 +494,9 @@ static int create_impl(pfslam_handle *h)
     h->own_stream = true;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const size_t n = h->n, M = (size_t)h->dimx * h->dimy;
     CHK(dalloc(&h->x, n)); CHK(dalloc(&h->y, n)); CHK(dalloc(&h->th, n)); CHK(dalloc(&h->w, n)); CHK(dalloc(&h->wm, n));
     CHK(dalloc(&h->x2, n)); CHK(dalloc(&h->y2, n)); CHK(dalloc(&h->th2, n));
@@ -604,6 +614,9 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->h_scan) (void)hipHostFree(h->h_scan);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

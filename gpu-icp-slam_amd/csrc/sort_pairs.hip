@@ -1,5 +1,5 @@
 // sort_pairs.hip -- 30-bit key / int value radix sort (hipCUB/rocPRIM) used to order particles along a
-// Morton curve before scoring.  Kept in its own translation unit: the rocPRIM headers dominate compile time.
+// space-filling curve before scoring.  Kept in its own translation unit: the rocPRIM headers dominate compile time.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
                                                   pf::KdView tree, const int *__restrict__ order, int direct,
                                                   float *__restrict__ out)
 {
-    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int j0 = blockIdx.y * beams_per_chunk;
     const int j1 = min(nb, j0 + beams_per_chunk);
     if (slot >= n) return;
@@ -979,7 +979,10 @@ static int launch_score(pfslam_handle *h)
     else if (h->planar) {
         // PFSLAM_DBG_LDS: pad the launch with dynamic LDS to cap the occupancy (bound-ness experiments only)
         static const int dbg_lds = getenv("PFSLAM_DBG_LDS") ? atoi(getenv("PFSLAM_DBG_LDS")) : 0;
-        hipLaunchKernelGGL(k_score_kd<true>, grid, dim3(256), dbg_lds, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
+        // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
+        // (2.387 vs 2.400 ms with 256-thread groups)
+        const int blk = 64;
+        hipLaunchKernelGGL(k_score_kd<true>, dim3((h->n + blk - 1) / blk, used), dim3(blk), dbg_lds, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
                            bpc, kd_view(h), order, direct, out);
     }
     else

@@ -371,9 +371,17 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
 {
     int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= n) return;
-    // sequential chunk order (deterministic for any weights); loads are independent, so keep 16 of them in flight
+    // sequential chunk order (deterministic for any weights; with one beam per chunk -- small N -- it is the reference's own
+    // beam order); loads are independent, so keep 64, then 16, of them in flight
     float a = 0.0f;
     int c = 0;
+    for (; c + 64 <= chunks; c += 64) {
+        float v[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) v[k] = partial[(size_t)(c + k) * n + slot];
+#pragma unroll
+        for (int k = 0; k < 64; k++) a += v[k];
+    }
     for (; c + 16 <= chunks; c += 16) {
         float v[16];
 #pragma unroll

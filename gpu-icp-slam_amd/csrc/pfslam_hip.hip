@@ -130,7 +130,8 @@ struct pfslam_handle {
     int *d_count = nullptr;
     // host mirrors / read-back
     // device->host: [HostHeader | new walls (float4 x max_wall)], one copy per step into pinned memory
-    uint8_t *d_out = nullptr, *h_out = nullptr;
+    uint8_t *d_out = nullptr, *h_out = nullptr, *out_dev = nullptr; // out_dev: where the kernels write (d_out, or h_out's device view)
+    bool zero_copy = false;
     size_t out_bytes = 0;
     // host->device: packed tree updates of a step (new nodes + patched parents), one copy + one scatter kernel
     uint8_t *d_upd = nullptr, *h_upd = nullptr;
@@ -559,9 +560,20 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->d_count, 4));
     h->out_bytes = sizeof(HostHeader) + (size_t)h->max_wall * 16;
     CHK(dalloc(&h->d_out, h->out_bytes));
-    h->new_pts = (float4 *)(h->d_out + sizeof(HostHeader));
     HIPCHK(hipHostMalloc((void **)&h->h_out, h->out_bytes));
     memset(h->h_out, 0, h->out_bytes);
+    // Zero-copy hand-over: the last kernels of a frame write the 64-byte header and the new walls straight into the pinned
+    // host buffer, and the patch kernel reads the packed node updates straight out of pinned host memory -- no D2H / H2D copy
+    // commands around the frame's host sync (PFSLAM_ZEROCOPY=0 restores the staged copies for A/B).
+    h->zero_copy = !(getenv("PFSLAM_ZEROCOPY") && atoi(getenv("PFSLAM_ZEROCOPY")) == 0);
+    if (h->zero_copy) {
+        void *dp = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dp, h->h_out, 0));
+        h->out_dev = (uint8_t *)dp;
+    } else {
+        h->out_dev = h->d_out;
+    }
+    h->new_pts = (float4 *)(h->out_dev + sizeof(HostHeader));
     h->upd_bytes = 64 + (size_t)((h->max_wall + 3) & ~3) * (16 + 4 + 4 + 4 + 4 + 16 + 4);
     CHK(dalloc(&h->d_upd, h->upd_bytes));
     HIPCHK(hipHostMalloc((void **)&h->h_upd, h->upd_bytes));

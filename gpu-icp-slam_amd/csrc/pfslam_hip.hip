@@ -979,9 +979,9 @@ static int launch_score(pfslam_handle *h)
         CHK(timer_pair(h, tp));
         HIPCHK(hipEventRecord(tp.first, h->stream));
     }
-    // variant 3 = LDS-staged tree top.  Measured on MI355X (100 k particles, 100 k-point map): 2.71 ms vs 2.64 ms for the
-    // plain kernel -- the kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ all SIMD cycles), not L1-bound, and the 16-wave
-    // blocks the 48 KB image needs schedule more coarsely; a persistent-block version was slower still (3.5 ms).
+    // variant 3 = LDS-staged tree top.  Measured on MI355X (100 k particles, 100 k-point map): 2.48 ms vs 2.41 ms for the plain
+    // kernel although it issues 25 % fewer gathers -- the TA path, VALU issue and the 8-wave latency budget saturate together
+    // (DESIGN.md section 4); a persistent-block version was slower still (3.5 ms).  Variants 3-5 are kept for A/B only.
     const bool use_lds = h->planar && h->top_levels > 0 && h->variant == 3;
     if (use_lds && h->top_exit_stale) {
         CHK(refresh_top_exit(h));

@@ -29,9 +29,16 @@ class GpuBuffers:
     def __init__(self, eng, torch, device):
         self.torch = torch
 
+        cache = {}
+
         def view(which, typestr, itemsize, dtype):
+            # wrapping a pointer costs ~20 us; the pose buffers only alternate between two addresses, so keep the wrappers
             ptr, nbytes = eng.device_ptr(which)
-            return torch.as_tensor(_DevView(ptr, nbytes, typestr, itemsize), device=torch.device("cuda", device)).view(dtype)
+            key = (ptr, nbytes, typestr)
+            t = cache.get(key)
+            if t is None:
+                t = cache[key] = torch.as_tensor(_DevView(ptr, nbytes, typestr, itemsize), device=torch.device("cuda", device)).view(dtype)
+            return t
 
         self.stats = view(0, "<i8", 8, torch.int64)
         self.start = view(8, "<f4", 4, torch.float32)
@@ -56,7 +63,11 @@ class ShardedSlam:
         if engine is None:
             engine = pkg.PfSlam(self.n, device=device, global_offset=rank * self.n, global_n=n_global, **kw)
             if torch is not None:
-                # run the kernels on torch's current stream so RCCL collectives and kernels are stream-ordered
+                # run the kernels on torch's current stream so RCCL collectives and kernels are stream-ordered; a stream of
+                # our own rather than the legacy null stream, which synchronises implicitly with every blocking stream
+                if torch.cuda.current_stream().cuda_stream == 0:
+                    self._stream = torch.cuda.Stream(device=device)
+                    torch.cuda.set_stream(self._stream)
                 engine.set_stream(torch.cuda.current_stream().cuda_stream)
             buffers = GpuBuffers(engine, torch, device)
         self.eng, self.buf = engine, buffers

@@ -108,3 +108,30 @@ def test_lidar_reads_the_reference_mat_format(tmp_path, pkg, compress):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mat2bin.py"), str(mat), str(conv)], stdout=subprocess.DEVNULL)
     got = np.fromfile(str(conv), np.float32).reshape(-1, 1081)
     assert (got == np.delete(scans, 4, axis=0)).all()
+
+
+@pytest.mark.gpu
+def test_cpp_bench_driver_matches_python_driver(tmp_path, pkg):
+    """host/pfslam_bench (C++ on the bare C-ABI): same map, scans and frame numbers as a Python-driven handle give the
+    same final pose bits and map size, and it prints the throughput line."""
+    import json
+    assert pkg.device_count() > 0
+    build_host(pkg)
+    pts, segs = pkg.synth.make_map_points(20000, seed=1)
+    tree = pkg.kd_create(pts)
+    scans = np.stack([pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f) for f in range(8)]).astype(np.float32)
+    (tmp_path / "map.nodes").write_bytes(tree.tobytes())
+    scans.tofile(str(tmp_path / "scans.f32"))
+    out = subprocess.check_output([os.path.join(HOST, "pfslam_bench"), str(tmp_path / "map.nodes"), str(tmp_path / "scans.f32"),
+                                   "3000", "5", "3", "6"]).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    h = pkg.PfSlam(3000, kd_capacity=len(tree) + (1 << 17))
+    h.set_map(tree)
+    for f in range(1, 6):
+        h.motion_update(f)
+    for k in range(8):
+        h.step(6 + k, scans[k])
+    assert d["steps"] == 5 and d["warmup"] == 3 and d["particles"] == 3000 and d["value"] > 0
+    assert d["kd_size_end"] == h.trace()["kd_size"]
+    assert np.allclose(d["pose"], h.pose, atol=5e-7)   # printed with 6 decimals
+    h.close()

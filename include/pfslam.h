@@ -23,6 +23,13 @@
  *   pfslam_resample                    PFResample / kernWeightedSample    kernel.cu:420-511
  *   pfslam_score_grid/update_map_grid  kernEvaluateParticles / PFUpdateMap kernel.cu:243-372,513-621
  *   pfslam_kd_create/insert/balance    KDTree::Create/InsertNode/Balance  kdtree.cpp:25-105
+ *   pfslam_step_grid                   the frame loop of kernel.cu:1702-1762 with the 2-D stages
+ *                                      PFMeasurementUpdate / PFUpdateMap  kernel.cu:307-339, 551-577
+ *   pfslam_traverse                    findCorrespondenceIndexKD          kernel.cu:924-972
+ *   pfslam_topology_update, find_walls,
+ *   check_loop_closure, get_topology   UpdateTopology / FindWalls / CheckLoopClosure   kernel.cu:623-795
+ *   pfslam_shard_begin / shard_finish  particleFilter split where a multi-GPU caller merges shards (no reference counterpart:
+ *                                      the reference is single-GPU)
  */
 #ifndef PFSLAM_H
 #define PFSLAM_H

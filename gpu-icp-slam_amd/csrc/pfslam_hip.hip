@@ -145,6 +145,7 @@ struct pfslam_handle {
     // ICP needs only the scan, the previous pose and the map (kernel.cu:974-1075): it runs on `aux` under the score kernel
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool header_packed = false;   // k_test_new already filled the frame's HostHeader
     bool icp_forked = false;      // aux work in flight (between fork_icp and join_icp)
     bool icp_delta_ready = false; // joined: icp_dbg[24..27] holds this frame's increment, not yet added to the best particle
     bool masks_cleared = false;   // the aux stream already zeroed the free / wall masks for this frame
@@ -946,7 +947,14 @@ static int score_chunks(const pfslam_handle *h)
     return chunks;
 }
 
-static int launch_score(pfslam_handle *h)
+__global__ void k_reduce_partials_minmax(const float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats);
+template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
+static int join_icp(pfslam_handle *h);
+static int launch_stats_reset(pfslam_handle *h, hipStream_t st);
+
+// fuse_minmax: the frame loops want the packed min/max keys of this shard right away; the reduce kernel then produces them
+// too (one launch less on the chain).  Needs more than one beam chunk, which every launch below ~8 M particles has.
+static int launch_score(pfslam_handle *h, bool fuse_minmax = false)
 {
     if (h->kd_size <= 0) return fail("pfslam_score_kd: no map loaded");
     const int chunks = score_chunks(h);
@@ -1013,10 +1021,26 @@ static int launch_score(pfslam_handle *h)
         HIPCHK(hipEventRecord(tp.second, h->stream));
         h->ev_pending.push_back(tp);
     }
-    if (used > 1) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n,
-                           used, order, h->fit);
+    if (fuse_minmax) {
+        if (h->icp_forked) CHK(join_icp(h)); // the aux stream reset the keys
+        if (!h->stats_clean) CHK(launch_stats_reset(h, h->stream));
+        h->stats_clean = false;
+    }
+    if (used > 1 && fuse_minmax) {
+        hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n, used, order,
+                           h->fit, h->goff, (long long *)h->stats);
         HIPCHK(hipGetLastError());
+    } else {
+        if (used > 1) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n,
+                               used, order, h->fit);
+            HIPCHK(hipGetLastError());
+        }
+        if (fuse_minmax) { // single chunk: the score kernel wrote fit directly
+            const int blocks = std::min(1024, (h->n + 255) / 256);
+            hipLaunchKernelGGL(k_minmax<float>, dim3(blocks), dim3(256), 0, h->stream, (const float *)h->fit, h->n, h->goff, (long long *)h->stats);
+            HIPCHK(hipGetLastError());
+        }
     }
     return 0;
 }

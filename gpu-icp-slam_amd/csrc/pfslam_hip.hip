@@ -97,6 +97,7 @@ struct pfslam_handle {
     // space-filling-curve processing order of the particles (performance only; results do not depend on it)
     unsigned *mkey = nullptr, *mkey2 = nullptr;
     int *order = nullptr, *order2 = nullptr;
+    int *cells = nullptr; // counting sort of the lane order: [2^18 cell counts | 2^18 cursors | 256 tile totals]
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int64_t *stats = nullptr;
@@ -434,6 +435,122 @@ __global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ x
     idx[i] = i;
 }
 
+// ------------------------------------------------------------------------------------------
+// Lane order in 3 launches instead of k_morton_keys + hipCUB's 10-launch merge sort: a counting sort over 2^18 Hilbert cells
+// laid over the particle cloud itself (64 cells per dimension across +-3.2 sigma around the mean, both estimated from the first
+// 1024 slots -- slots are exchangeable).  At 100 k particles the cells are as fine as the 2 mm / 1 mrad cells of the sorted
+// keys and almost every particle has a cell of its own, so the order inside a cell (atomic arrival order) does not matter.
+// The order only decides which lane scores which particle; results do not depend on it.
+//   k_cell_count:   cell of every particle (kept in `cell[]`), histogram with global atomics
+//   k_cell_scan:    exclusive scan inside 1024-cell tiles + tile totals (256 blocks); the counts are zeroed for the next frame
+//   k_cell_scatter: slot = tile offset + atomicAdd(cursor[cell]) -> order[slot] = particle
+// ------------------------------------------------------------------------------------------
+#define PF_CELL_BITS 6
+#define PF_CELLS (1 << (3 * PF_CELL_BITS))
+__device__ __forceinline__ unsigned spread6(unsigned v) // 6 bits -> every third bit
+{
+    v &= 0x3fu;
+    v = (v | (v << 8)) & 0x300fu;
+    v = (v | (v << 4)) & 0x30c3u;
+    v = (v | (v << 2)) & 0x9249u;
+    return v;
+}
+__device__ __forceinline__ float block_sum_256(float v, float *red)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ th, int n, unsigned *__restrict__ cell,
+                                                    int *__restrict__ hist)
+{
+    __shared__ float red[4];
+    const int ns = min(n, 1024); // cloud statistics, identical in every block
+    float sx = 0, sy = 0, st = 0;
+    for (int k = threadIdx.x; k < ns; k += 256) { sx += x[k]; sy += y[k]; st += th[k]; }
+    const float inv = 1.0f / (float)ns;
+    const float mx = block_sum_256(sx, red) * inv, my = block_sum_256(sy, red) * inv, mt = block_sum_256(st, red) * inv;
+    float vx = 0, vy = 0, vt = 0;
+    for (int k = threadIdx.x; k < ns; k += 256) {
+        const float a = x[k] - mx, b = y[k] - my, c = th[k] - mt;
+        vx += a * a; vy += b * b; vt += c * c;
+    }
+    // 64 cells over +-3.2 sigma: cell = 0.1 sigma, never finer than 0.25 mm / 0.125 mrad
+    const float cx = 1.0f / fmaxf(0.1f * sqrtf(block_sum_256(vx, red) * inv), 2.5e-4f);
+    const float cy = 1.0f / fmaxf(0.1f * sqrtf(block_sum_256(vy, red) * inv), 2.5e-4f);
+    const float ct = 1.0f / fmaxf(0.1f * sqrtf(block_sum_256(vt, red) * inv), 1.25e-4f);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned X[3] = {(unsigned)fminf(fmaxf((th[i] - mt) * ct + 32.0f, 0.0f), 63.0f),
+                     (unsigned)fminf(fmaxf((x[i] - mx) * cx + 32.0f, 0.0f), 63.0f),
+                     (unsigned)fminf(fmaxf((y[i] - my) * cy + 32.0f, 0.0f), 63.0f)};
+    const unsigned M = 1u << (PF_CELL_BITS - 1); // Hilbert index, Skilling's axes-to-transpose
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (X[a] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    const unsigned c = (spread6(X[0]) << 2) | (spread6(X[1]) << 1) | spread6(X[2]);
+    cell[i] = c;
+    atomicAdd(&hist[c], 1);
+}
+// 256 blocks: exclusive scan inside every 1024-cell tile + the tile totals; the counts are zeroed for the next frame
+__global__ __launch_bounds__(256) void k_cell_scan(int *__restrict__ hist, int *__restrict__ cursor, int *__restrict__ tile_tot)
+{
+    __shared__ int wtot[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    const int4 v = *(const int4 *)(hist + c0);
+    *(int4 *)(hist + c0) = make_int4(0, 0, 0, 0);
+    const int s = v.x + v.y + v.z + v.w;
+    int inc = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int base = inc - s;
+    for (int k = 0; k < wave; k++) base += wtot[k];
+    *(int4 *)(cursor + c0) = make_int4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+    if (threadIdx.x == 255) tile_tot[blockIdx.x] = base + s;
+}
+__global__ __launch_bounds__(256) void k_cell_scatter(const unsigned *__restrict__ cell, int n, int *__restrict__ cursor,
+                                                      const int *__restrict__ tile_tot, int *__restrict__ order)
+{
+    // offsets of the 256 tiles: every block scans the tile totals itself (256 values)
+    __shared__ int tile_off[PF_CELLS / 1024];
+    __shared__ int wtot[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = tile_tot[threadIdx.x];
+    int inc = t;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int base = inc - t;
+    for (int k = 0; k < wave; k++) base += wtot[k];
+    tile_off[threadIdx.x] = base;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const unsigned c = cell[i];
+        order[tile_off[c >> 10] + atomicAdd(&cursor[c], 1)] = i;
+    }
+}
+
 // ---- findCorrespondenceIndexKD (kernel.cu:924-972) over an arbitrary xyz batch --------------
 template <bool PLANAR>
 __global__ __launch_bounds__(256) void k_traverse(const float *__restrict__ xyz, int n, pf::KdView tree,
@@ -537,6 +654,8 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->top_pos, (size_t)PF_TOP_SLOTS)); CHK(dalloc(&h->top_orig, (size_t)PF_TOP_SLOTS)); CHK(dalloc(&h->top_exit, (size_t)PF_TOP_SLOTS + 1));
     CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
     CHK(dalloc(&h->mkey, n)); CHK(dalloc(&h->mkey2, n)); CHK(dalloc(&h->order, n)); CHK(dalloc(&h->order2, n));
+    CHK(dalloc(&h->cells, (size_t)2 * PF_CELLS + PF_CELLS / 1024));
+    HIPCHK(hipMemsetAsync(h->cells, 0, ((size_t)2 * PF_CELLS + PF_CELLS / 1024) * sizeof(int), h->stream));
     if (pfslam_sort_pairs_u32(nullptr, &h->sort_tmp_bytes, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, nullptr))
         return fail("pfslam_create: radix sort workspace query failed");
     HIPCHK(hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
@@ -637,7 +756,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw, h->top_pos, h->top_orig, h->top_exit,
-                    h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
+                    h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->cells, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
                     h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->d_out, h->d_upd};
@@ -972,7 +1091,17 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false)
         out = h->partial;
     }
     const int *order = nullptr;
-    if (h->variant != 1 && h->n > 64) { // variant 1 = identity order (A/B of the lane ordering)
+    // default up to 400 k particles: counting sort over Hilbert cells of the cloud (3 launches; step 2.58 vs 2.61 ms at 100 k,
+    // 0.477 vs 0.496 ms at 10 k).  Beyond that several particles share a cell and the full sort's finer order wins
+    // (1 M particles: 22.55 vs 22.67 ms).
+    if (h->variant != 1 && h->variant != 6 && h->n > 64 && h->n <= 400000) {
+        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->mkey, h->cells);
+        hipLaunchKernelGGL(k_cell_scan, dim3(PF_CELLS / 1024), dim3(256), 0, h->stream, h->cells, h->cells + PF_CELLS, h->cells + 2 * PF_CELLS);
+        hipLaunchKernelGGL(k_cell_scatter, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->mkey, h->n, h->cells + PF_CELLS,
+                           h->cells + 2 * PF_CELLS, h->order2);
+        HIPCHK(hipGetLastError());
+        order = h->order2;
+    } else if (h->variant != 1 && h->n > 64) { // large N, or variant 6 (A/B): 30-bit Hilbert keys + hipCUB sort; variant 1 = identity order
         hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose,
                            h->mkey, h->order);
         size_t tb = h->sort_tmp_bytes;

@@ -178,7 +178,8 @@ int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
  * launch; pfslam_get_timers -> [total ms, launches, 0, 0].  pfslam_set_timing also resets the accumulators. */
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[4]);
-/* scoring kernel variant (all bit-identical; for A/B measurements): 0 = default (lanes ordered along a Hilbert curve), 1 = identity lane
+/* scoring kernel variant (all bit-identical; for A/B measurements): 0 = default (lanes ordered along a Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys
+ * above), 6 = always the sorted 30-bit keys, 1 = identity lane
  * order, 3 = default + LDS-staged tree top, 4 = default + two interleaved beams per lane, 5 = default + re-descents of 4 beams batched
  * per lane (3-5 are measured-and-slower experiments kept for A/B) */
 int pfslam_set_variant(pfslam_handle *h, int variant);

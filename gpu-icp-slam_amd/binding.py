@@ -17,7 +17,7 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_finish", "pfslam_debug_graph_probe", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_map", "pfslam_shard_finish", "pfslam_debug_graph_probe", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
@@ -93,6 +93,7 @@ def load():
     L.pfslam_step_grid.argtypes = [vp, i32, vp]
     L.pfslam_shard_begin.argtypes = [vp, i32, vp, vp]
     L.pfslam_shard_finish.argtypes = [vp, i32, vp, vp]
+    L.pfslam_shard_map.argtypes = [vp]
     L.pfslam_get_pose.argtypes = [vp, vp]
     L.pfslam_get_particles.argtypes = [vp, vp, vp]
     L.pfslam_get_map.argtypes = [vp, vp, vp]
@@ -357,6 +358,9 @@ class PfSlam:
         seeded = C.c_int(0)
         _chk(self.L.pfslam_shard_begin(self._h, frame, _p(scan), C.byref(seeded)), "pfslam_shard_begin")
         return bool(seeded.value)
+
+    def shard_map(self):
+        _chk(self.L.pfslam_shard_map(self._h), "pfslam_shard_map")
 
     def shard_finish(self, frame):
         did, neff = C.c_int(0), C.c_float(0)

@@ -146,6 +146,7 @@ struct pfslam_handle {
     // ICP needs only the scan, the previous pose and the map (kernel.cu:974-1075): it runs on `aux` under the score kernel
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool shard_map_done = false;  // pfslam_shard_map already launched this frame's map-update chain
     bool header_packed = false;   // k_test_new already filled the frame's HostHeader
     bool icp_forked = false;      // aux work in flight (between fork_icp and join_icp)
     bool icp_delta_ready = false; // joined: icp_dbg[24..27] holds this frame's increment, not yet added to the best particle

@@ -104,12 +104,13 @@ class ShardedSlam:
         e.measurement_apply(fetch=False)        # weights + this rank's share of the best pose
         if self.world > 1:
             d.all_reduce(b.start, op=d.ReduceOp.SUM)
-        # the weights are final after measurement_apply: gather them while the (replicated) ICP runs
+        # the weights are final after measurement_apply: gather them while the (replicated) map update runs
         pending = self._all_gather(b.gw, b.w, async_op=True)
-        e.icp(None, fetch=False)
+        e.icp(None, fetch=False)                # adds the increment of the solve that ran under the score kernel
+        e.shard_map()                           # replicated map update (device part): the all-gather runs under it
         if pending is not None:
             pending.wait()                      # stream-level: orders the compute stream behind the collective
-        did, neff = e.shard_finish(frame)       # map update, Neff on the global weights, resample plan; the one host sync
+        did, neff = e.shard_finish(frame)       # Neff on the global weights, header, the one host sync, resample plan
         if did:
             local, glob = b.pose_views()
             for dst, src in zip(glob, local):

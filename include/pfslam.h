@@ -161,9 +161,11 @@ int pfslam_measurement_local(pfslam_handle *h);  /* score must have run; fills t
 int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, float *fmax); /* after the all-reduce */
 /* The sharded frame in two calls (one host sync per frame, like pfslam_step); the caller's collectives run between
  * them on the handle's stream:  shard_begin -> all-reduce MAX of buffer 0 -> pfslam_measurement_apply -> all-reduce SUM
- * of buffer 8 + all-gather of buffer 5 into buffer 10 -> pfslam_icp -> shard_finish -> if *resampled: all-gather of
+ * of buffer 8 + all-gather of buffer 5 into buffer 10 -> pfslam_icp -> pfslam_shard_map -> (wait for the all-gather) -> shard_finish -> if *resampled: all-gather of
  * buffers 2-4 into 11-13 -> pfslam_resample_gather.  *seeded = 1 when the frame only seeded the map (first scan). */
 int pfslam_shard_begin(pfslam_handle *h, int frame, const float *scan_host, int *seeded);
+int pfslam_shard_map(pfslam_handle *h); /* optional, between pfslam_icp and the wait for the weight all-gather: the replicated
+                                         * map update's device chain, so that the all-gather runs under it */
 int pfslam_shard_finish(pfslam_handle *h, int frame, int *resampled, float *neff);
 /* device pointers of the handle's buffers, for zero-copy wrapping by the harness.
  * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta, 5 w (n x f32 each), 6 weight tile sums,

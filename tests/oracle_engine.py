@@ -154,9 +154,12 @@ class OracleShardEngine:
         self.measurement_local()
         return False
 
-    def shard_finish(self, frame):
-        """pfslam_shard_finish: map update at the ICP pose, then Neff / resample plan on the gathered weights."""
+    def shard_map(self):
+        """pfslam_shard_map: the replicated map update at the ICP pose."""
         self.update_map_kd()
+
+    def shard_finish(self, frame):
+        """pfslam_shard_finish: Neff / resample plan on the gathered weights."""
         return self.resample_plan(frame)
 
     def icp(self, start=None, fetch=True):

@@ -9,16 +9,27 @@ pose, Bresenham map update (with host insert of new walls), Neff + weighted resa
 north_star / configs[2], synthetic because data/train_lidar*.mat is absent from the reference checkout):
 100 000 particles per GPU x 1081-beam synthetic scans against a 100 000-point KD map.  Particles shard over the
 GPUs (weak scaling); the map and scan are replicated; the merges are tiny RCCL collectives.
+BASELINE configs[3]'s per-GPU share is `--particles 125000 --map-points 500000`.
 
 One JSON line on rank 0:  value = particles scored per second over the whole job, with the map, particles and
 all state resident in HBM (the 4.3 KB scan per frame is the step API's input and is inside the timed region).
-"roofline" prices the dominant kernel (scan-match score) by SURVEY 8d's algorithmic bytes; "cpu_baseline" times
-the CPU oracle's restatement of the same scoring loop on this box's host cores (a reported baseline, not the target).
+
+"roofline" prices the dominant kernel (k_score_kd) against the resource that binds it -- the CU's gather path (texture
+addresser: 4 lane addresses per clock for 64-bit and wider loads, i.e. 64 B/clk per CU for the 16-byte node records) --
+with everything measured in this run: the kernel time by HIP events around the timed launches, the gathers it issues by
+a counting instantiation of the same kernel (pfslam_score_census) before and after the timed region, the chip's gather
+rate by a micro-benchmark (pfslam_ubench_gather).  Sub-blocks: "hbm" = counter bytes of the newest matching rocprofv3 PMC
+summary under profiles/ (never a fixed file) against the 8 TB/s HBM peak; "alg_equiv" = SURVEY 8d's algorithmic bytes
+(B_valid x V x 32 B + 20 B per evaluation), which are L1/L2 hits and therefore NOT a fraction of anything.
+"cpu_baseline" times the CPU oracle's restatement of the same scoring loop on this box's usable host cores (a reported
+baseline, not the target); "long_run" is the same step over a whole 100-frame KDTree::Balance cycle.
 """
 import argparse
+import glob
 import importlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -30,7 +41,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FIRST_FRAME = 6        # frame numbers only seed the RNG; start past the frame%100==5 re-balance
+FIRST_FRAME = 6        # frame numbers seed the RNG and decide the frame % 100 == 5 re-balance; see "long_run" in the line
 
 
 def parse():
@@ -41,50 +52,109 @@ def parse():
     ap.add_argument("--particles", type=int, default=100000, help="particles per GPU")
     ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs, the long-run leg and the extras (profiling runs)")
+    ap.add_argument("--pmc-file", default="", help="rocprofv3 PMC summary to take roofline.traffic from (default: newest matching profiles/r*_pmc_score_kd*.json)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend gloo)")
     return ap.parse_args()
 
 
-def cpu_baseline(O, tree, particles, scan, sample):
-    """Oracle restatement of EvaluateParticleKD (the reference has no CPU version of it) on a bounded sample."""
-    cores = os.cpu_count() or 1
+def host_cpu():
+    """Usable host cores (scheduler affinity AND the cgroup CPU quota) and the CPU model."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return cores, model, os.cpu_count() or cores
+
+
+def cpu_baseline(O, tree, particles, scan, sample, map_points):
+    """Oracle restatement of EvaluateParticleKD (the reference has no CPU version of it) on a bounded sample: one thread
+    (the reference's CPU style) and one thread per usable core."""
+    cores, model, logical = host_cpu()
     one = min(len(particles), 512)
     t0 = time.perf_counter()
     fit1, visits, valid = O.score_kd(tree, particles[:one], scan, stats=True)
     t1 = time.perf_counter() - t0
     rate1 = one / t1
+    # does the lease really deliver `cores` cores?  try the affinity count and fall back to what scales
     if sample <= 0:  # ~10-20 s of CPU core time, at least 64 particles per thread
-        sample = int(min(len(particles), max(one, 64 * cores, rate1 * 15)))
+        sample = int(min(len(particles), max(one, 64 * cores, rate1 * 12)))
     best = None
     for _ in range(3):  # best of 3 (thread start-up noise)
         t0 = time.perf_counter()
         O.score_kd(tree, particles[:sample], scan, threads=cores)
         tm = time.perf_counter() - t0
         best = tm if best is None else min(best, tm)
-    tm = best
     return {
-        "value": sample / tm, "unit": "particle-scan evals/s", "cores": cores, "kind": "port",
-        "sample": "%d particles x 1081 beams, 100k-point map, oracle A5 restatement, %d pthreads, -O3 -mavx2 -mfma "
-                  "(single thread: %.0f evals/s on %d particles)" % (sample, cores, rate1, one),
+        "value": sample / best, "unit": "particle-scan evals/s", "cores": cores, "kind": "port",
+        "cpu_model": model, "logical_cpus": logical,
+        "single_thread_value": rate1, "all_core_speedup": (sample / best) / rate1,
+        "sample": "%d particles x 1081 beams on the end-of-run %d-point map, oracle restatement of kernEvaluateParticlesKD "
+                  "(gcc -O3 -mavx2 -mfma), %d pthreads = usable cores (sched affinity and cgroup quota; %d logical CPUs); "
+                  "single thread: %.0f evals/s on %d particles" % (sample, map_points, cores, logical, rate1, one),
     }, visits / max(valid, 1), valid / one
+
+
+def find_pmc(explicit, n_local, map_points):
+    """Newest committed rocprofv3 PMC summary of k_score_kd for THIS workload (profiles/rNN_pmc_score_kd*.json)."""
+    if explicit:
+        return explicit if os.path.exists(explicit) else None
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_score_kd*.json")):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        wl = d.get("workload", {"particles": 100000, "map_points": 100000})  # r01 predates the key: default workload
+        if wl.get("particles") != n_local or wl.get("map_points") != map_points:
+            continue
+        key = (int(m.group(1)) if m else 0, os.path.getmtime(f))
+        if best is None or key > best[0]:
+            best = (key, f)
+    return best[1] if best else None
 
 
 def extras(pkg, O, tree, pts, scan, device):
     """Side measurements for DESIGN.md (not part of the contract line's metric): the host map structure next to the
-    reference's own kdtree.cpp (oracle/_ref, kind "reference"), and the 2-D grid scoring path (BASELINE configs[0-1])."""
+    reference's own kdtree.cpp (oracle/_ref, kind "reference"), and the 2-D grid path (BASELINE configs[0-1]) with the
+    reference's CPU branches (H7) timed beside pfslam_step_grid."""
     ex = {}
     try:
         t0 = time.perf_counter(); pkg.kd_create(pts); t1 = time.perf_counter() - t0
-        ex["kd_create_100k_ms"] = {"product_host": t1 * 1e3}
+        ex["kd_create_ms"] = {"points": len(pts), "product_host": t1 * 1e3}
         ref = O.ref_kdtree()
         if ref is not None:
             buf = np.zeros(len(pts), O.NODE_DTYPE)
             t0 = time.perf_counter(); ref.ref_kd_create(O.P(pts), len(pts), O.P(buf)); t2 = time.perf_counter() - t0
-            ex["kd_create_100k_ms"]["reference_kdtree_cpp"] = t2 * 1e3
-            ex["kd_create_100k_ms"]["identical_output"] = bool(buf.tobytes() == pkg.kd_create(pts).tobytes())
+            ex["kd_create_ms"]["reference_kdtree_cpp"] = t2 * 1e3
+            ex["kd_create_ms"]["identical_output"] = bool(buf.tobytes() == pkg.kd_create(pts).tobytes())
         # grid path: 10 k particles, 1600x1600 int8 grid rasterised from the same walls
         n = 10000
         grid = np.full((1600, 1600), -100, np.int8)
@@ -111,25 +181,33 @@ def extras(pkg, O, tree, pts, scan, device):
                                          "cpu_oracle_1thread_evals_per_s": 2048 / tc, "parity_sample_ok": bool((fit[:256] == want).all())}
         h.close()
         # whole 2-D frame loop (BASELINE configs[1]: 10 k particles) and configs[0]'s 50 particles, on a short drive
-        _, frames = pkg.synth.corridor_sequence(30, seed=5)
+        _, frames = pkg.synth.corridor_sequence(60, seed=5)
         for nn, key in ((10000, "grid_step_10k_particles"), (50, "grid_step_50_particles")):
             h = pkg.PfSlam(nn, device=device)
             for f in range(1, 11):
                 h.step_grid(f, frames[f - 1][1])
             h.synchronize()
             t0 = time.perf_counter()
-            for f in range(11, 31):
+            for f in range(11, 61):
                 h.step_grid(f, frames[f - 1][1])
             h.synchronize()
-            dt = (time.perf_counter() - t0) / 20
+            dt = (time.perf_counter() - t0) / 50
             ex[key] = {"ms_per_frame": dt * 1e3, "evals_per_s": nn / dt}
             h.close()
-        o = O.Slam(50)
-        t0 = time.perf_counter()
-        for f in range(1, 31):
-            o.step_grid(f, frames[f - 1][1])
-        ex["grid_step_50_particles"]["cpu_oracle_1thread_ms_per_frame"] = (time.perf_counter() - t0) / 30 * 1e3
-        o.close()
+        # BASELINE configs[0]: 50 particles on the reference's own CPU branches (GPU_* == 0, kernel.cu:340-369, 578-620,
+        # 487-508; H7 semantics), one thread -- next to pfslam_step_grid at 50 particles above
+        for label, fn in (("cpu_branch_reference_semantics", "step_grid_cpu"), ("gpu_branch_semantics_on_cpu", "step_grid")):
+            o = O.Slam(50)
+            step = getattr(o, fn)
+            for f in range(1, 11):
+                step(f, frames[f - 1][1])
+            t0 = time.perf_counter()
+            for f in range(11, 61):
+                step(f, frames[f - 1][1])
+            ex["grid_step_50_particles"]["cpu_oracle_1thread_ms_per_frame_" + label] = (time.perf_counter() - t0) / 50 * 1e3
+            o.close()
+        ex["grid_step_50_particles"]["note"] = ("configs[0]: reference CPU 2-D path (oracle restatement of the GPU_*==0 branches, "
+                                                "1 thread) vs pfslam_step_grid on the GPU, 50 particles, 50 frames")
     except Exception as e:  # extras must never break the contract line
         ex["error"] = repr(e)
     return ex
@@ -165,19 +243,22 @@ def main():
     n_global = n_local * world
     pts, segs = pkg.synth.make_map_points(a.map_points, seed=1)
     tree = pkg.kd_create(pts)
-    n_frames = a.warmup + a.steps
+    long_run = not a.no_cpu_baseline
+    n_frames = a.warmup + a.steps + (130 if long_run else 0)
     scans = []
     for f in range(n_frames):
         pose = (0.002 * f, 0.001 * f, 0.0004 * f)
         scans.append(pkg.synth.make_scan(segs, pose, seed=2000 + f))
 
+    cap = a.map_points + (1 << 18)
     if distributed:
         from importlib import import_module
         sharded = import_module("gpu-icp-slam_amd.sharded")
-        eng = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=a.map_points + (1 << 17), dist=dist, torch=torch)
+        eng = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch)
         eng.want_best = False
     else:
-        eng = pkg.PfSlam(n_local, kd_capacity=a.map_points + (1 << 17), device=local_rank)
+        eng = pkg.PfSlam(n_local, kd_capacity=cap, device=local_rank)
+    e0 = eng.eng if hasattr(eng, "eng") else eng
     eng.set_map(tree)
     if a.variant:
         eng.set_variant(a.variant)
@@ -188,6 +269,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(k0, count, frame0):
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(count):
+            eng.step(frame0 + k, scans[k0 + k])
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     # initial condition: a particle cloud already dispersed around the start pose (5 dispersion steps), so that the
     # first scoring launches behave like steady state instead of scoring 100 k coincident particles
     for f in range(1, 6):
@@ -196,19 +290,16 @@ def main():
     for k in range(a.warmup):
         eng.step(frame, scans[k]); frame += 1
     barrier()
+    census0 = e0.score_census() if rank == 0 else None   # what a scoring launch issues on the state the timed region starts from
     eng.set_timing(1)
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        eng.step(frame, scans[a.warmup + k]); frame += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(a.warmup, a.steps, frame)
+    frame += a.steps
     timers = eng.timers()
+    eng.set_timing(0)
     trace = eng.trace()
+    census1 = e0.score_census() if rank == 0 else None   # ... and on the state it ends with
 
+    out = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = n_global * a.steps / dt
@@ -220,52 +311,103 @@ def main():
             "config": {"workload": "synthetic 1081-beam scans, %d particles/GPU, %d-point KD map, full SLAM step "
                                    "(disperse+score+weights+ICP/SVD+map update+resample)" % (n_local, a.map_points),
                        "particles_global": n_global, "parallelism": "particles sharded x%d, map replicated" % world,
+                       "frames": "%d..%d (KDTree::Balance falls on frame %% 100 == 5: not inside this window, see long_run)" % (frame - a.steps, frame - 1),
                        "kd_size_end": trace.get("kd_size")},
         }
-        # ---- roofline of the dominant kernel (rank 0's launches) + CPU baseline and extras (N = 1 only) ----
-        if True:
+        import oracle_lib as O
+        # ---- roofline of the dominant kernel (rank 0's launches) -------------------------------------
+        tree_end = np.ascontiguousarray(e0.map(), dtype=O.NODE_DTYPE)
+        p_end = np.ascontiguousarray(e0.particles(), dtype=O.PARTICLE_DTYPE)
+        last_scan = scans[a.warmup + a.steps - 1]
+        if a.no_cpu_baseline or world > 1:
+            _, visits, valid = O.score_kd(tree_end, p_end[:128], last_scan, stats=True)
+            vbar, bvalid = visits / max(valid, 1), valid / 128
+        else:
+            cb, vbar, bvalid = cpu_baseline(O, tree_end, p_end, last_scan, a.cpu_sample, len(tree_end))
+            out["cpu_baseline"] = cb
+        launches = max(timers["score_launches"], 1)
+        kern_s = max(timers["score_ms"] / launches, 1e-9) * 1e-3
+        ub = e0.ubench_gather()
+        # wave-level gathers per launch: mean of the census before and after the timed region.  A descent-loop trip is one
+        # 16-byte wave gather; a parent-hyperplane test one 16-byte + one 4-byte wave gather.
+        g16 = 0.5 * ((census0["trips"] + census0["tests"]) + (census1["trips"] + census1["tests"]))
+        g4 = 0.5 * (census0["tests"] + census1["tests"])
+        lane_visits = 0.5 * (census0["visits"] + census1["visits"])
+        gather_bytes = g16 * 64 * 16 + g4 * 64 * 4           # lane-level bytes the TA path moves per launch
+        achieved = gather_bytes / kern_s / 1e9
+        peak_measured = ub["wave_gathers_per_s"] * 1024.0 / 1e9
+        peak_nominal = ub["cus"] * 64.0 * ub["nominal_ghz"]  # 64 B/clk per CU (4 lanes x 16 B) at the nominal clock, GB/s
+        pmc_path = find_pmc(a.pmc_file, n_local, a.map_points)
+        traffic, clock_ghz, pmc = None, None, None
+        if pmc_path:
+            try:
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("hbm_bytes_per_launch")
+                gui = pmc.get("avg_per_launch", {}).get("GRBM_GUI_ACTIVE")
+                kms = pmc.get("kernel_ms")
+                if gui and kms:
+                    clock_ghz = gui / 8.0 / (kms * 1e-3) / 1e9   # GRBM_GUI_ACTIVE sums the 8 XCDs
+            except Exception:
+                traffic = None
+        alg_bytes_per_eval = bvalid * vbar * 32.0 + 20.0     # B_valid x V x 32 B + 16 B in + 4 B out
+        out["roofline"] = {
+            "bound": "l1_gather", "achieved": achieved, "peak": peak_measured, "unit": "GB/s", "frac": achieved / peak_measured,
+            "traffic": traffic,
+            "kernel": "k_score_kd", "kernel_ms": kern_s * 1e3, "launches": launches, "kernel_evals_per_s": n_local / kern_s,
+            "definition": "achieved = lane-level bytes of the wave gathers one launch issues (16 B x 64 lanes per node-record gather, "
+                          "4 B x 64 per parent-index gather; counted by pfslam_score_census before and after the timed region, mean) / "
+                          "HIP-event time of the timed launches; peak = wave-gather rate of this chip measured in this process "
+                          "(pfslam_ubench_gather: cache-resident table, 8 waves/SIMD) x 1024 B",
+            "gathers": {"wave_gathers_16B_per_launch": g16, "wave_gathers_4B_per_launch": g4, "lane_visits_per_launch": lane_visits,
+                        "lanes_active_per_trip": lane_visits / max(0.5 * (census0["trips"] + census1["trips"]), 1.0),
+                        "census_before": census0, "census_after": census1,
+                        "oracle_min_wave_gathers": n_local / 64.0 * bvalid * vbar},
+            "ubench": dict(ub, peak_nominal_GBs=peak_nominal,
+                           note="peak_nominal = CUs x 64 B/clk x nominal clock; the measured rate is what the same "
+                                "gather instruction sustains on this box"),
+            "frac_of_nominal_peak": achieved / peak_nominal,
+            "hbm": None if traffic is None else {
+                "bytes_per_launch": traffic, "achieved": traffic / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS, "source": os.path.relpath(pmc_path, ROOT),
+                "measured_clock_ghz": clock_ghz,
+                "note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes (gfx950 correction of MI355X_MICROARCH.md); the map "
+                        "records are cache resident, compulsory HBM traffic is ~20 B per evaluation + the beam-chunk partials"},
+            "alg_equiv": {"bytes_per_eval": alg_bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
+                          "GBs": alg_bytes_per_eval * n_local / kern_s / 1e9,
+                          "note": "SURVEY 8d's algorithmic node bytes (B_valid x V x 32 B + 20 B): served from L1/L2, "
+                                  "not an HBM statement and not a fraction of any peak"},
+        }
+
+    # ---- the same step over a whole balance cycle (every rank takes part; rank 0 reports) ----------
+    if long_run:
+        # continue to the next frame % 100 == 6, then time exactly 100 frames: one KDTree::Balance (frame % 100 == 5) inside
+        k = a.warmup + a.steps
+        while frame % 100 != 6 and k < n_frames - 100:
+            eng.step(frame, scans[k]); frame += 1; k += 1
+        if frame % 100 == 6 and k + 100 <= n_frames:
+            dtl = timed(k, 100, frame)
+            frame += 100; k += 100
+            if out is not None:
+                out["long_run"] = {"frames": 100, "first_frame": frame - 100, "ms_per_step": dtl / 100 * 1e3,
+                                   "value": n_global * 100 / dtl, "unit": "particle-scan evals/s",
+                                   "includes": "one KDTree::Balance (host re-build + upload of the whole map, kernel.cu:1707-1711) "
+                                               "and the map growing between two balances", "kd_size_end": eng.trace().get("kd_size")}
+        if not distributed and k + 20 <= n_frames:  # per-phase split, as the reference prints it (kernel.cu:1754-1759)
+            eng.set_timing(2)
+            for j in range(20):
+                eng.step(frame, scans[k + j]); frame += 1
+            eng.synchronize()
+            t = eng.timers()
+            eng.set_timing(0)
+            if out is not None:
+                out["phases_ms"] = {name: t[name + "_ms"] / max(t[name + "_count"], 1) for name in ("motion", "measurement", "map", "resample")}
+                out["phases_ms"]["note"] = ("HIP events on the step's stream, mean of 20 frames: motion = dispersion; measurement = lane "
+                                            "order + scan-match + reduce/min/max + weights + Neff (ICP runs under it); map = device chain + "
+                                            "host insert and its sync; resample = averaged over all frames (most do not resample)")
+    if out is not None:
+        if world == 1 and not a.no_cpu_baseline:
             import oracle_lib as O
-            # the oracle measures V (mean node visits of the reference traversal) and the CPU rate on the map and the
-            # particle cloud as they are at the END of the timed region (the map grows where the scan lands)
-            e0 = eng.eng if hasattr(eng, "eng") else eng
-            tree_end = np.ascontiguousarray(e0.map(), dtype=O.NODE_DTYPE)
-            p0 = np.ascontiguousarray(e0.particles(), dtype=O.PARTICLE_DTYPE)
-            last_scan = scans[n_frames - 1]
-            if a.no_cpu_baseline or world > 1:
-                _, visits, valid = O.score_kd(tree_end, p0[:128], last_scan, stats=True)
-                vbar, bvalid = visits / max(valid, 1), valid / 128
-            else:
-                cb, vbar, bvalid = cpu_baseline(O, tree_end, p0, last_scan, a.cpu_sample)
-                out["cpu_baseline"] = cb
-            bytes_per_eval = bvalid * vbar * 32.0 + 20.0  # B_valid x V x 32 B + 16 B in + 4 B out
-            launches = max(timers["score_launches"], 1)
-            kern_ms = max(timers["score_ms"] / launches, 1e-9)
-            achieved = bytes_per_eval * n_local / (kern_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_score_kd.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_score_kd", "kernel_ms": kern_ms, "launches": launches,
-                               "alg_bytes_per_eval": bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
-                               "kernel_evals_per_s": n_local / (kern_ms * 1e-3),
-                               # one of the units that saturate in this kernel: one wave-level gather per
-                               # node visit, ~16 TA cycles each per CU.  Lower bound on the gathers: perfectly coherent waves.
-                               "gather_issue": {
-                                   "wave_gathers_per_launch_min": n_local / 64.0 * bvalid * vbar,
-                                   "rate_min_per_s": n_local / 64.0 * bvalid * vbar / (kern_ms * 1e-3),
-                                   "peak_per_s": 256 * 2.4e9 / 16.0,
-                                   "frac_min": n_local / 64.0 * bvalid * vbar / (kern_ms * 1e-3) / (256 * 2.4e9 / 16.0),
-                                   "note": "peak = 256 CUs x 2.4 GHz / 16 cycles per wave gather (tools/ubench/gather_rate.hip); "
-                                           "the PMC count of gathers is ~10 % above this minimum (profiles/r01_pmc_memory_path.json)"},
-                               "note": "algorithmic node bytes are served from L2/L1 (the 1.6 MB hot tree is cache "
-                                       "resident); compulsory HBM traffic is ~20 B/eval, hence frac can exceed 1"}
-            if world == 1:
-                out["extras"] = extras(pkg, O, tree, pts, scans[0], local_rank)
+            out["extras"] = extras(pkg, O, tree, pts, scans[0], local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

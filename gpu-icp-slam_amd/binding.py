@@ -17,14 +17,14 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_map", "pfslam_shard_finish", "pfslam_debug_graph_probe", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_map", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
-    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_debug_math", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_debug_census",
+    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_score_census", "pfslam_ubench_gather",
 ]
 
 
@@ -119,7 +119,8 @@ def load():
     L.pfslam_find_walls.argtypes = [vp, vp, vp, vp]
     L.pfslam_check_loop_closure.argtypes = [vp, vp, i32, vp]
     L.pfslam_get_topology.argtypes = [vp, vp, i32, vp, vp]
-    L.pfslam_debug_census.argtypes = [vp, vp, i32]
+    L.pfslam_score_census.argtypes = [vp, vp]
+    L.pfslam_ubench_gather.argtypes = [vp, vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -231,9 +232,13 @@ class PfSlam:
         _chk(self.L.pfslam_set_timing(self._h, int(enable)), "pfslam_set_timing")
 
     def timers(self):
-        out = (C.c_double * 4)()
+        out = (C.c_double * 12)()
         _chk(self.L.pfslam_get_timers(self._h, out), "pfslam_get_timers")
-        return {"score_ms": out[0], "score_launches": int(out[1])}
+        d = {"score_ms": out[0], "score_launches": int(out[1])}
+        for k, name in enumerate(("motion", "measurement", "map", "resample"), start=1):
+            d[name + "_ms"] = out[2 * k]
+            d[name + "_count"] = int(out[2 * k + 1])
+        return d
 
     def synchronize(self):
         _chk(self.L.pfslam_synchronize(self._h), "pfslam_synchronize")
@@ -327,10 +332,16 @@ class PfSlam:
         _chk(self.L.pfslam_get_topology(self._h, _p(nodes), cap, C.byref(n), C.byref(idx)), "pfslam_get_topology")
         return nodes[:n.value].copy(), idx.value
 
-    def debug_census(self, reset=True):
+    def score_census(self):
+        """One counting launch of the score kernel on the current state (see include/pfslam.h)."""
         out = (C.c_ulonglong * 4)()
-        _chk(self.L.pfslam_debug_census(self._h, out, int(reset)), "pfslam_debug_census")
-        return [int(v) for v in out]
+        _chk(self.L.pfslam_score_census(self._h, out), "pfslam_score_census")
+        return {"trips": int(out[0]), "visits": int(out[1]), "tests": int(out[2]), "test_lanes": int(out[3])}
+
+    def ubench_gather(self):
+        out = (C.c_double * 4)()
+        _chk(self.L.pfslam_ubench_gather(self._h, out), "pfslam_ubench_gather")
+        return {"wave_gathers_per_s": out[0], "cus": int(out[1]), "nominal_ghz": out[2], "cycles_per_wave_gather": out[3]}
 
     def resample_plan(self, frame):
         did, neff = C.c_int(), C.c_float()

@@ -11,10 +11,6 @@
 
 namespace pf {
 
-#ifdef PF_EXP_COUNT /* experiment: loop-trip / active-lane census of the traversal */
-__device__ unsigned long long g_trip_census[4]; // [0] wave trips in the descent loop, [1] active lanes summed, [2] parent tests (wave), [3] lanes in them
-#endif
-
 struct KdView {
     const uint4 *hot;   // {x bits, y bits, left (30-bit two's complement) | axis<<30, right}
     const float *z;     // node z; for a PLANAR map (all z == 0): the true left child of z-level nodes, as int bits
@@ -23,20 +19,19 @@ struct KdView {
     int planar;         // every node has z == 0
 };
 
+// Traversal census (pfslam_score_census): what one launch of the score kernel really issued.  Filled by the CENSUS
+// instantiation of the kernel only -- the timed instantiation carries none of this.
+struct KdCensus {
+    unsigned long long trips;        // wave-level trips of the descent loop = wave-level 16-byte gathers of node records
+    unsigned long long lanes;        // active lanes summed over those trips = node visits
+    unsigned long long tests;        // wave-level parent-hyperplane tests (each: one 4-byte + one 16-byte wave gather)
+    unsigned long long test_lanes;   // lanes in them
+};
+
 // In a planar map a z-level node (axis 2) always sends the query right (0 < 0 is false).  Its hot record therefore
 // stores the RIGHT child in both link fields -- the descent needs no axis test -- and the true left child, which only
 // the parent-hyperplane re-descent can reach, moves to the (otherwise all-zero) z side array.
 __host__ __device__ __forceinline__ int hot_left(uint32_t la) { return ((int)(la << 2)) >> 2; } // sign-extend 30 bits
-
-// Top of the tree staged in LDS (planar maps): the first `levels` levels in BFS order (slot 0 = root,
-// children of slot s = 2s+1, 2s+2), which a median-split tree always fills completely and whose split
-// axis is level % 3.  pos/orig live in LDS, exit[] (global) maps the BFS slots of level `levels` to node indices.
-struct KdTop {
-    const float2 *pos; // LDS: node (x, y) per BFS slot
-    const int *orig;   // LDS: node index per BFS slot
-    const int *exit;   // global: node index (or -1) of the 2^levels children below the staged part
-    int levels;
-};
 
 __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, int left, int right, bool planar)
 {
@@ -57,6 +52,7 @@ __host__ __device__ __forceinline__ uint4 pack_hot(float x, float y, int axis, i
 
 // Tree gathers go through buffer descriptors: a 32-bit byte offset (one shift) instead of a sign-extended 64-bit flat
 // address per visit -- measured 2.40 vs 2.46 ms for the score kernel.  The descriptors are wave-uniform (SGPRs).
+// idx << 4 must stay below the descriptor's 0x7ffffff0 bytes: pfslam_create bounds kd_capacity by 2^27 - 1 nodes.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t kd_rsrc_t;
 __device__ __forceinline__ kd_rsrc_t kd_rsrc(const void *base)
@@ -66,12 +62,7 @@ __device__ __forceinline__ kd_rsrc_t kd_rsrc(const void *base)
 __device__ __forceinline__ uint4 kd_load_hot(kd_rsrc_t r, int idx)
 {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#ifdef PF_EXP_IDXEN /* experiment: structured addressing (descriptor stride 16): the hardware scales the index, no shift */
-    u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 idxen\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(idx), "s"(r) : "memory");
-#else
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, idx << 4, 0, 0);
-#endif
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ int kd_load_i32(kd_rsrc_t r, int idx)
@@ -84,6 +75,16 @@ __device__ kd_rsrc_t kd_rsrc(const void *base);
 __device__ uint4 kd_load_hot(kd_rsrc_t r, int idx);
 __device__ int kd_load_i32(kd_rsrc_t r, int idx);
 #endif
+
+// one wave-level event of the census: the first active lane adds (1, active lanes)
+__device__ __forceinline__ void census_add(unsigned long long *ev, unsigned long long *lanes)
+{
+    const unsigned long long ex = __builtin_amdgcn_read_exec();
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+        atomicAdd(ev, 1ull);
+        atomicAdd(lanes, (unsigned long long)__popcll(ex));
+    }
+}
 
 // The traversal of kernel.cu:881-919 (== 931-969, 1147-1184, 1239-1276): greedy descent, then
 // while the best node changed, one look at the best node's parent hyperplane and a re-descent of
@@ -98,130 +99,17 @@ __device__ int kd_load_i32(kd_rsrc_t r, int idx);
 // H1: the reference reads tree[-1] when the best node is the root; here the search stops.
 #define PF_GUARD_K 0.999999523162841796875f /* 1 - 2^-21 */
 
-template <bool PLANAR, bool USE_TOP = false>
-__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, const KdTop top = KdTop{})
+template <bool PLANAR, bool CENSUS = false>
+__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, KdCensus *census = nullptr)
 {
     // bestDist starts as the distance to the root; visiting the root first reproduces that state
     float sBest = INFINITY;
     int bestIdx = 0, prevBest = -1, head = 0;
-    if (USE_TOP) {
-        float sGuard = INFINITY;
-        // Phase 1: the staged levels.  Every lane is at the same level, so the split axis is wave-uniform, there is
-        // no loop divergence, and a step costs one ds_read_b64 instead of a 16-byte gather through the L1.
-        int slot = 0, bestSlot = 0;
-        for (int lvl = 0; lvl < top.levels; lvl++) {
-            const float2 nd = top.pos[slot];
-            const float dx = nd.x - px, dy = nd.y - py;
-            const float s = dx * dx + dy * dy;
-            bool take = s < sGuard;
-            const bool inBand = (s < sBest) & !take;
-            if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
-                float sb = sBest;
-                asm volatile("" : "+v"(sb));
-                take = take | (inBand && fsqrt(s) < fsqrt(sb));
-            }
-            sBest = take ? s : sBest;
-            sGuard = take ? s * PF_GUARD_K : sGuard;
-            bestSlot = take ? slot : bestSlot;
-            const int axis = lvl % 3; // scalar
-            const bool lt = axis == 0 ? (px < nd.x) : axis == 1 ? (py < nd.y) : false;
-            slot = 2 * slot + (lt ? 1 : 2);
-        }
-        bestIdx = top.orig[bestSlot];
-        head = top.exit[slot - ((1 << top.levels) - 1)];
-    }
-#ifdef PF_FIRST_DESCENT_SPECIAL
-    if (PLANAR && !USE_TOP) {
-        // First descent from the root: every lane of the wave is at the same depth in every trip, and the split axis
-        // of a node is depth % 3, so the three trips of an x / y / z round need no per-node axis decode (and a planar
-        // z-level simply continues right).  Lanes that run off the tree skip the remaining steps; the wave leaves the
-        // round-robin together, which keeps the survivors in phase.  Re-descents start at arbitrary depths and use the
-        // generic loop below.
-        for (;;) {
-#pragma unroll
-            for (int ax = 0; ax < 3; ax++) {
-                if (head >= 0) {
-#ifdef PF_EXP_COUNT
-                    {
-                        const unsigned long long ex = __builtin_amdgcn_read_exec();
-                        if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
-                            atomicAdd(&g_trip_census[0], 1ull);
-                            atomicAdd(&g_trip_census[1], (unsigned long long)__popcll(ex));
-                        }
-                    }
-#endif
-                    const uint4 nd = t.hot[head];
-                    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
-                    const float dx = nx - px, dy = ny - py;
-                    const float s = dx * dx + dy * dy;
-                    const float sGuard = sBest * PF_GUARD_K;
-                    bool take = s < sGuard;
-                    const bool inBand = (s < sBest) != take;
-                    if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
-                        float sb = sBest;
-                        asm volatile("" : "+v"(sb));
-                        take = take | (inBand && fsqrt(s) < fsqrt(sb));
-                    }
-                    sBest = take ? s : sBest;
-                    bestIdx = take ? head : bestIdx;
-                    if (ax == 0)
-                        head = (px < nx) ? hot_left(nd.z) : (int)nd.w;
-                    else if (ax == 1)
-                        head = (py < ny) ? hot_left(nd.z) : (int)nd.w;
-                    else
-                        head = (int)nd.w;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(head >= 0) == 0ull) break;
-        }
-    }
-#endif
-#ifdef PF_EXP_IDXEN
-    const kd_rsrc_t hot_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(t.hot), /*stride*/ 16, /*records*/ 0x7ffffff, 0x00020000);
-    const kd_rsrc_t parent_rsrc = kd_rsrc(t.parent);
-#else
     const kd_rsrc_t hot_rsrc = kd_rsrc(t.hot), parent_rsrc = kd_rsrc(t.parent);
-#endif
     for (;;) {
         while (head >= 0) { // greedy descent
-#ifdef PF_EXP_COUNT
-            {
-                const unsigned long long ex = __builtin_amdgcn_read_exec();
-                if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
-                    atomicAdd(&g_trip_census[0], 1ull);
-                    atomicAdd(&g_trip_census[1], (unsigned long long)__popcll(ex));
-                }
-            }
-#endif
-#if defined(PF_EXP_UNIFORM_SLOAD) /* experiment: when the whole wave stands on one node, fetch it through the scalar cache */
-            uint4 nd;
-            {
-                const int uh = __builtin_amdgcn_readfirstlane(head);
-                if (__builtin_amdgcn_ballot_w64(head != uh) == 0ull) {
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4 r;
-                    const uint4 *p = t.hot + uh;
-                    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
-                    nd.x = r.x; nd.y = r.y; nd.z = r.z; nd.w = r.w;
-                } else {
-                    nd = kd_load_hot(hot_rsrc, head);
-                }
-            }
-#else
+            if (CENSUS) census_add(&census->trips, &census->lanes);
             const uint4 nd = kd_load_hot(hot_rsrc, head);
-#endif
-#ifdef PF_EXP_EXTRA_VALU /* bound-ness experiment: 10 extra dependent VALU per visit, kept alive through sBest */
-            {
-                float e = __uint_as_float(nd.x);
-#pragma unroll
-                for (int k = 0; k < 10; k++) e = e * 1.0000001f + 1e-30f;
-                if (e == 12345.678f) sBest = 0.0f;
-            }
-#endif
-#ifdef PF_EXP_EXTRA_LOAD /* bound-ness experiment: a second 16-byte gather per visit, kept alive through sBest */
-            const uint4 nd2 = t.hot[head ^ 1];
-            if (nd2.x == 0x7fc12345u) sBest = 0.0f;
-#endif
             // (node - query) as a 2-vector: v_pk_add_f32 / v_pk_mul_f32, one rounding per component as in the scalar form
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 nxy = {__uint_as_float(nd.x), __uint_as_float(nd.y)};
@@ -265,15 +153,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         }
         // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
         if (bestIdx == prevBest) break;
-#ifdef PF_EXP_COUNT
-        {
-            const unsigned long long ex = __builtin_amdgcn_read_exec();
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
-                atomicAdd(&g_trip_census[2], 1ull);
-                atomicAdd(&g_trip_census[3], (unsigned long long)__popcll(ex));
-            }
-        }
-#endif
+        if (CENSUS) census_add(&census->tests, &census->test_lanes);
         prevBest = bestIdx;
         const float bestDist = fsqrt(sBest);
         const int pi = kd_load_i32(parent_rsrc, bestIdx);
@@ -305,129 +185,13 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
     return bestIdx;
 }
 
-// Two independent queries per lane, interleaved (ILP 2): the traversal is a chain of dependent L1 gathers and the
-// score kernel is latency-bound at the hardware limit of 8 waves per SIMD (halving the occupancy doubles its time),
-// so a second query per lane is the remaining way to put more loads in flight.  Semantics per query are exactly
-// kd_nearest_ref<true>'s; a query with valid == false is skipped.
-struct KdQuery {
-    float px, py, sBest, sGuard;
-    int bestIdx, prevBest, head;
-};
-
-__device__ __forceinline__ void kd_visit_planar(KdQuery &q, const uint4 nd, const bool active, bool &inBand)
-{
-    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
-    const float dx = nx - q.px, dy = ny - q.py;
-    const float s = dx * dx + dy * dy;
-    const bool take = active & (s < q.sGuard);
-    inBand = active & (s < q.sBest) & !take;
-    q.sBest = take ? s : q.sBest;
-    q.sGuard = take ? s * PF_GUARD_K : q.sGuard;
-    q.bestIdx = take ? q.head : q.bestIdx;
-    const uint32_t axis = nd.z >> 30;
-    const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
-    const bool lt = pa < na;
-    const int next = lt ? hot_left(nd.z) : (int)nd.w;
-    q.head = active ? next : q.head;
-}
-
-// the rare guard-band case of one visit, resolved exactly (see kd_nearest_ref)
-__device__ __forceinline__ void kd_band_fix(KdQuery &q, const uint4 nd, const int visited, const bool inBand)
-{
-    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
-    const float dx = nx - q.px, dy = ny - q.py;
-    float s = dx * dx + dy * dy, sb = q.sBest;
-    asm volatile("" : "+v"(sb));
-    const bool take = inBand && fsqrt(s) < fsqrt(sb);
-    q.sBest = take ? s : q.sBest;
-    q.sGuard = take ? s * PF_GUARD_K : q.sGuard;
-    q.bestIdx = take ? visited : q.bestIdx;
-}
-
-// end of a descent: nodeFullyExplored test + parent hyperplane check; sets head to the far child or leaves it < 0
-// and returns whether the query is finished
-__device__ __forceinline__ bool kd_after_descent_planar(const KdView &t, KdQuery &q)
-{
-    if (q.bestIdx == q.prevBest) return true;
-    q.prevBest = q.bestIdx;
-    const float bestDist = fsqrt(q.sBest);
-    const int pi = t.parent[q.bestIdx];
-    if (pi < 0) return true; // H1
-    const uint4 nd = t.hot[pi];
-    const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
-    const uint32_t axis = nd.z >> 30;
-    const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
-    const float hd = axis < 2 ? fabsf(pa - na) : 0.0f;
-    const bool lt = (pa < na) & (axis < 2);
-    if (!(hd < bestDist)) return true;
-    q.head = lt ? (int)nd.w : (axis == 2 ? __float_as_int(t.z[pi]) : hot_left(nd.z));
-    return false; // an empty far side (head < 0) ends at the next after-descent test (best unchanged)
-}
-
-// the descent loop of kd_nearest_ref<true> on its own (batched kernel): from q.head until it runs off the tree
-__device__ __forceinline__ void kd_descend_planar(const KdView &t, KdQuery &q)
-{
-    while (q.head >= 0) {
-        const uint4 nd = t.hot[q.head];
-        const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
-        const float dx = nx - q.px, dy = ny - q.py;
-        const float s = dx * dx + dy * dy;
-        bool take = s < q.sGuard;
-        const bool inBand = (s < q.sBest) != take;
-        if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
-            float sb = q.sBest;
-            asm volatile("" : "+v"(sb));
-            take = take | (inBand && fsqrt(s) < fsqrt(sb));
-        }
-        q.sBest = take ? s : q.sBest;
-        q.sGuard = take ? s * PF_GUARD_K : q.sGuard;
-        q.bestIdx = take ? q.head : q.bestIdx;
-        const uint32_t axis = nd.z >> 30;
-        const float pa = axis == 0 ? q.px : q.py, na = axis == 0 ? nx : ny;
-        q.head = (pa < na) ? hot_left(nd.z) : (int)nd.w;
-    }
-}
-
-__device__ __forceinline__ void kd_nearest_ref_x2(const KdView &t, KdQuery &a, KdQuery &b, bool doneA, bool doneB)
-{
-    a.sBest = a.sGuard = b.sBest = b.sGuard = INFINITY;
-    a.bestIdx = b.bestIdx = 0;
-    a.prevBest = b.prevBest = -1;
-    a.head = doneA ? -1 : 0;
-    b.head = doneB ? -1 : 0;
-    for (;;) {
-        for (;;) {
-            const bool actA = a.head >= 0, actB = b.head >= 0;
-            if (!(actA | actB)) break;
-            const int ia = actA ? a.head : 0, ib = actB ? b.head : 0;
-            const uint4 ndA = t.hot[ia];
-            const uint4 ndB = t.hot[ib];
-            bool bandA, bandB;
-            kd_visit_planar(a, ndA, actA, bandA);
-            kd_visit_planar(b, ndB, actB, bandB);
-            if (__builtin_amdgcn_ballot_w64(bandA | bandB) != 0ull) {
-                kd_band_fix(a, ndA, ia, bandA);
-                kd_band_fix(b, ndB, ib, bandB);
-            }
-        }
-        if (!doneA) doneA = kd_after_descent_planar(t, a);
-        if (!doneB) doneB = kd_after_descent_planar(t, b);
-        if (doneA & doneB) break;
-    }
-}
-
 // LIDAR_ANGLE(i) (kernel.cu:42) + CleanLidarScan (kernel.cu:182-187)
 __device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)
 {
     const float PI_F = 3.1415926535897932384626422832795028841971f; // utilities.h:12
     float rot = fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f) + theta;
     float s, c;
-#ifdef PF_EXP_FAST_TRIG /* experiment: cost share of the fp64 sincos specification (results are NOT bit-exact) */
-    s = __sinf(rot);
-    c = __cosf(rot);
-#else
     sincosf_spec(rot, s, c);
-#endif
     x = range * c;
     y = range * s;
 }

@@ -30,8 +30,8 @@
 #define PF_SUM_TILE 4096
 #define PF_SCAN_TILE 1024
 #define PF_SCAN_CHUNK 16
-#define PF_TOP_LEVELS 12 /* tree levels staged in LDS by the score kernel variant 3 */
-#define PF_TOP_SLOTS ((1 << PF_TOP_LEVELS) - 1)
+enum { PF_T_SCORE = 0, PF_T_MOTION, PF_T_MEASURE, PF_T_MAP, PF_T_RESAMPLE, PF_TIMER_SLOTS };
+#define PF_KD_MAX_NODES ((1 << 27) - 1) /* idx << 4 must fit the 0x7ffffff0-byte buffer descriptor; links are 30-bit */
 
 extern "C" int pfslam_sort_pairs_u32(void *tmp, size_t *tmp_bytes, const unsigned *keys_in, unsigned *keys_out,
                                      const int *vals_in, int *vals_out, int n, int end_bit, void *stream);
@@ -86,11 +86,7 @@ struct pfslam_handle {
     int *parent = nullptr;
     float *kz = nullptr, *kw = nullptr;
     std::vector<pfslam_node> h_nodes; // host mirror (topology + positions; w refreshed on demand)
-    // LDS-staged top of the tree (BFS order)
-    float2 *top_pos = nullptr;
-    int *top_orig = nullptr, *top_exit = nullptr;
-    int top_levels = 0;
-    std::vector<int> h_top_orig;
+    bool integral_w = true; // every map weight is an integer (true for every map the SLAM step itself produces)
     // scoring
     float *fit = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
@@ -138,7 +134,6 @@ struct pfslam_handle {
     uint8_t *d_upd = nullptr, *h_upd = nullptr;
     size_t upd_bytes = 0;
     float *h_scan = nullptr; // pinned staging of the scan
-    bool top_exit_stale = false;
     std::vector<pfslam_particle> h_particles;
     std::vector<float> h_tmp;
     int32_t trace[8] = {0};
@@ -153,10 +148,16 @@ struct pfslam_handle {
     bool masks_cleared = false;   // the aux stream already zeroed the free / wall masks for this frame
     bool stats_clean = false;     // ... and reset the min/max keys
     // live timing of the dominant kernel inside pfslam_step (bench.py roofline leg)
+    // timing == 1: HIP events bracket every k_score_kd launch (bench.py roofline leg).  timing == 2: also the four phases the
+    // reference times per frame (kernel.cu:1727-1760): motion / measurement / map / resample.
     int timing = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_pending;
-    double score_ms = 0.0;
-    long score_launches = 0;
+    struct TimedSpan { hipEvent_t a, b; int slot; };
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<TimedSpan> ev_pending;
+    hipEvent_t phase_ev = nullptr; // start of the phase being timed
+    double timer_ms[PF_TIMER_SLOTS] = {0};
+    long timer_count[PF_TIMER_SLOTS] = {0};
+    pf::KdCensus *d_census = nullptr;
 };
 
 // ==========================================================================================
@@ -190,12 +191,13 @@ __global__ __launch_bounds__(256) void k_motion(float *__restrict__ x, float *__
 // near-identical poses, so their descents touch the same nodes until the last levels (one
 // cache line per step instead of 64) and the per-lane sum keeps the reference's beam order.
 // blockIdx.y selects the beam chunk; partial sums are combined by k_reduce_partials.
-template <bool PLANAR>
+// CENSUS: the same kernel counting its own loop trips (pfslam_score_census); never the timed instantiation.
+template <bool PLANAR, bool CENSUS = false>
 __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, const float *__restrict__ py,
                                                   const float *__restrict__ pth, int n,
                                                   const float *__restrict__ scan, int nb, int beams_per_chunk,
                                                   pf::KdView tree, const int *__restrict__ order, int direct,
-                                                  float *__restrict__ out)
+                                                  float *__restrict__ out, pf::KdCensus *__restrict__ census = nullptr)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int j0 = blockIdx.y * beams_per_chunk;
@@ -211,157 +213,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;
             wy += y;
-            const int b = pf::kd_nearest_ref<PLANAR>(tree, wx, wy, 0.0f);
-            acc += tree.w[b];
-        }
-    }
-    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
-}
-
-// Batched variant (variant 5): the sibling re-descents of PF_BATCH consecutive beams are worked off together.  A wave
-// spends about half of its loop trips in the re-descent rounds of a query, where only the lanes whose parent-hyperplane
-// test passed are active (~1/3); here every lane first runs the greedy descents of PF_BATCH beams (well-utilised), parks
-// the four states in LDS, and then walks through ITS OWN pending after-descent tests and re-descents, so a lane that is
-// done with one beam continues with the next instead of idling until the slowest lane of the wave finishes that beam.
-#define PF_BATCH 4
-__global__ __launch_bounds__(256) void k_score_kd_batched(const float *__restrict__ px, const float *__restrict__ py,
-                                                          const float *__restrict__ pth, int n,
-                                                          const float *__restrict__ scan, int nb, int beams_per_chunk,
-                                                          pf::KdView tree, const int *__restrict__ order, int direct,
-                                                          float *__restrict__ out)
-{
-    __shared__ float4 s_task[PF_BATCH][256]; // {px, py, sBest, bestIdx bits}; bestIdx < 0: beam rejected
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * beams_per_chunk;
-    const int j1 = min(nb, j0 + beams_per_chunk);
-    if (slot >= n) return; // no block-level barrier is used: every lane only touches its own LDS column
-    const int i = order ? order[slot] : slot;
-    const float x = px[i], y = py[i], th = pth[i];
-    float acc = 0.0f;
-    for (int jb = j0; jb < j1; jb += PF_BATCH) {
-        const int cnt = min(PF_BATCH, j1 - jb);
-        // phase 1: greedy descents from the root
-        for (int g = 0; g < cnt; g++) {
-            float wx, wy;
-            pf::clean_lidar_scan(jb + g, scan[jb + g], th, wx, wy);
-            pf::KdQuery q;
-            q.px = wx + x;
-            q.py = wy + y;
-            q.sBest = q.sGuard = INFINITY;
-            q.bestIdx = 0;
-            q.prevBest = -1;
-            const bool valid = fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE;
-            q.head = valid ? 0 : -1;
-            pf::kd_descend_planar(tree, q);
-            s_task[g][threadIdx.x] = make_float4(q.px, q.py, q.sBest, __int_as_float(valid ? q.bestIdx : -1));
-        }
-        // phase 2: per lane, in beam order: after-descent test, re-descent, ... until the beam is finished
-        int cur = 0;
-        pf::KdQuery q;
-        q.head = -1;
-        bool loaded = false;
-        for (;;) {
-            // settle tests until this lane has a re-descent to do or has no beam left
-            while (cur < cnt && q.head < 0) {
-                if (!loaded) {
-                    const float4 tk = s_task[cur][threadIdx.x];
-                    q.px = tk.x; q.py = tk.y; q.sBest = tk.z;
-                    q.sGuard = tk.z * PF_GUARD_K;
-                    q.bestIdx = __float_as_int(tk.w);
-                    q.prevBest = -1;
-                    loaded = true;
-                    if (q.bestIdx < 0) { // rejected beam contributes nothing
-                        cur++;
-                        loaded = false;
-                        continue;
-                    }
-                }
-                if (pf::kd_after_descent_planar(tree, q)) {
-                    acc += tree.w[q.bestIdx]; // beam order per lane is preserved
-                    cur++;
-                    loaded = false;
-                    q.head = -1;
-                }
-                // else: q.head is the far child (possibly < 0: an empty side; the next test then ends the beam)
-                else if (q.head < 0) continue;
-            }
-            if (__builtin_amdgcn_ballot_w64(cur < cnt) == 0ull) break;
-            pf::kd_descend_planar(tree, q); // lanes without work have head < 0
-        }
-    }
-    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
-}
-
-// ILP-2 variant: each lane interleaves the traversals of two consecutive beams (planar maps).
-__global__ __launch_bounds__(256) void k_score_kd_x2(const float *__restrict__ px, const float *__restrict__ py,
-                                                     const float *__restrict__ pth, int n,
-                                                     const float *__restrict__ scan, int nb, int beams_per_chunk,
-                                                     pf::KdView tree, const int *__restrict__ order, int direct,
-                                                     float *__restrict__ out)
-{
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * beams_per_chunk;
-    const int j1 = min(nb, j0 + beams_per_chunk);
-    if (slot >= n) return;
-    const int i = order ? order[slot] : slot;
-    const float x = px[i], y = py[i], th = pth[i];
-    float acc = 0.0f;
-    for (int j = j0; j < j1; j += 2) {
-        pf::KdQuery qa, qb;
-        float wx, wy;
-        pf::clean_lidar_scan(j, scan[j], th, wx, wy);
-        const bool va = fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE;
-        qa.px = wx + x;
-        qa.py = wy + y;
-        bool vb = false;
-        qb.px = qb.py = 0.0f;
-        if (j + 1 < j1) {
-            pf::clean_lidar_scan(j + 1, scan[j + 1], th, wx, wy);
-            vb = fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE;
-            qb.px = wx + x;
-            qb.py = wy + y;
-        }
-        pf::kd_nearest_ref_x2(tree, qa, qb, !va, !vb);
-        // beam order of the sum is kept: j, then j+1
-        if (va) acc += tree.w[qa.bestIdx];
-        if (vb) acc += tree.w[qb.bestIdx];
-    }
-    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
-}
-
-// Variant with the top PF_TOP_LEVELS tree levels staged in LDS (48 KB: positions + node ids of 4095 BFS slots).
-// 1024 threads per block, two blocks per CU -> 32 waves/CU share two LDS copies.
-__global__ __launch_bounds__(1024) void k_score_kd_lds(const float *__restrict__ px, const float *__restrict__ py,
-                                                       const float *__restrict__ pth, int n,
-                                                       const float *__restrict__ scan, int nb, int beams_per_chunk,
-                                                       pf::KdView tree, const float2 *__restrict__ top_pos,
-                                                       const int *__restrict__ top_orig, const int *__restrict__ top_exit,
-                                                       int levels, const int *__restrict__ order, int direct,
-                                                       float *__restrict__ out)
-{
-    __shared__ float2 s_pos[PF_TOP_SLOTS + 1];
-    __shared__ int s_orig[PF_TOP_SLOTS + 1];
-    const int nslots = (1 << levels) - 1;
-    for (int k = threadIdx.x; k < nslots; k += 1024) {
-        s_pos[k] = top_pos[k];
-        s_orig[k] = top_orig[k];
-    }
-    __syncthreads();
-    const int slot = blockIdx.x * 1024 + threadIdx.x;
-    const int j0 = blockIdx.y * beams_per_chunk;
-    const int j1 = min(nb, j0 + beams_per_chunk);
-    if (slot >= n) return;
-    const pf::KdTop top{s_pos, s_orig, top_exit, levels};
-    const int i = order ? order[slot] : slot;
-    const float x = px[i], y = py[i], th = pth[i];
-    float acc = 0.0f;
-    for (int j = j0; j < j1; j++) {
-        float wx, wy;
-        pf::clean_lidar_scan(j, scan[j], th, wx, wy);
-        if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
-            wx += x;
-            wy += y;
-            const int b = pf::kd_nearest_ref<true, true>(tree, wx, wy, 0.0f, top);
+            const int b = pf::kd_nearest_ref<PLANAR, CENSUS>(tree, wx, wy, 0.0f, census);
             acc += tree.w[b];
         }
     }
@@ -605,7 +457,7 @@ extern "C" void pfslam_default_config(pfslam_config *cfg)
     cfg->n_beams = 1081;
     cfg->map_scale_x = cfg->map_scale_y = 40.0f;
     cfg->map_res_x = cfg->map_res_y = 0.025f;
-    cfg->kd_capacity = 1 << 20;
+    cfg->kd_capacity = 10000000; // KD_MAX_SIZE, kernel.cu:77
     cfg->device = 0;
     cfg->strict_host_mirror = 1;
     cfg->free_upload_bug = 0;
@@ -652,7 +504,6 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->scan, (size_t)h->nb));
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
-    CHK(dalloc(&h->top_pos, (size_t)PF_TOP_SLOTS)); CHK(dalloc(&h->top_orig, (size_t)PF_TOP_SLOTS)); CHK(dalloc(&h->top_exit, (size_t)PF_TOP_SLOTS + 1));
     CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
     CHK(dalloc(&h->mkey, n)); CHK(dalloc(&h->mkey2, n)); CHK(dalloc(&h->order, n)); CHK(dalloc(&h->order2, n));
     CHK(dalloc(&h->cells, (size_t)2 * PF_CELLS + PF_CELLS / 1024));
@@ -721,6 +572,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     if (cfg->n_particles <= 0 || cfg->n_beams <= 0 || cfg->kd_capacity <= 0)
         return fail("pfslam_create: n_particles, n_beams and kd_capacity must be positive");
     if (cfg->n_particles > (1 << 24)) return fail("pfslam_create: at most 2^24 particles per handle");
+    if (cfg->kd_capacity > PF_KD_MAX_NODES) return fail("pfslam_create: kd_capacity above 2^27 - 1 nodes (32-bit byte offsets of the map records)");
     if (!(cfg->map_res_x > 0.0f && cfg->map_res_y > 0.0f && cfg->map_scale_x > 0.0f && cfg->map_scale_y > 0.0f))
         return fail("pfslam_create: map scale and resolution must be positive");
     {
@@ -729,7 +581,8 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
         // a wider map reads out of bounds, a taller one aliases rows.  Refuse instead of guessing a meaning.
         const int dx = (int)(cfg->map_scale_x / cfg->map_res_x), dy = (int)(cfg->map_scale_y / cfg->map_res_y);
         if (dx != dy) return fail("pfslam_create: the map must have as many cells in x as in y (reference cell index is x * dim.x + y)");
-        if (dx < 2 || (long long)dx * dy > (1ll << 28)) return fail("pfslam_create: map dimensions out of range");
+        // 16384 cells per side keeps every product of the closed-form Bresenham (k * deltay, cell index x * dim + y) inside int32
+        if (dx < 2 || dx > 16384) return fail("pfslam_create: map dimensions out of range (2 .. 16384 cells per side)");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -756,7 +609,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw, h->top_pos, h->top_orig, h->top_exit,
+    void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw,
                     h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->cells, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
@@ -774,8 +627,10 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->phase_ev) (void)hipEventDestroy(h->phase_ev);
+    if (h->d_census) (void)hipFree(h->d_census);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -800,30 +655,51 @@ extern "C" int pfslam_synchronize(pfslam_handle *h)
     return 0;
 }
 
-// HIP events bracket exactly the k_score_kd launch (on the stream it is launched on); pairs are collected lazily
+// Timed spans: pairs of HIP events on the stream the kernels are launched on, collected lazily.
 static int flush_timers(pfslam_handle *h)
 {
     for (auto &e : h->ev_pending) {
-        HIPCHK(hipEventSynchronize(e.second));
+        HIPCHK(hipEventSynchronize(e.b));
         float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
-        h->score_ms += ms;
-        h->score_launches += 1;
-        h->ev_pool.push_back(e);
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        h->timer_ms[e.slot] += ms;
+        h->timer_count[e.slot] += 1;
+        h->ev_pool.push_back(e.a);
+        h->ev_pool.push_back(e.b);
     }
     h->ev_pending.clear();
     return 0;
 }
-static int timer_pair(pfslam_handle *h, std::pair<hipEvent_t, hipEvent_t> &p)
+static int timer_event(pfslam_handle *h, hipEvent_t *e)
 {
     if (h->ev_pending.size() >= 512) CHK(flush_timers(h));
     if (h->ev_pool.empty()) {
-        HIPCHK(hipEventCreate(&p.first));
-        HIPCHK(hipEventCreate(&p.second));
+        HIPCHK(hipEventCreate(e));
     } else {
-        p = h->ev_pool.back();
+        *e = h->ev_pool.back();
         h->ev_pool.pop_back();
     }
+    return 0;
+}
+// phases of a frame (timing == 2): phase_begin records the start, phase_end closes the span into `slot` and starts the next
+static int phase_begin(pfslam_handle *h)
+{
+    if (h->timing < 2) return 0;
+    if (h->phase_ev) h->ev_pool.push_back(h->phase_ev);
+    CHK(timer_event(h, &h->phase_ev));
+    HIPCHK(hipEventRecord(h->phase_ev, h->stream));
+    return 0;
+}
+static int phase_end(pfslam_handle *h, int slot)
+{
+    if (h->timing < 2 || !h->phase_ev) return 0;
+    hipEvent_t e = nullptr;
+    CHK(timer_event(h, &e));
+    HIPCHK(hipEventRecord(e, h->stream));
+    h->ev_pending.push_back(pfslam_handle::TimedSpan{h->phase_ev, e, slot});
+    h->phase_ev = nullptr;
+    CHK(timer_event(h, &h->phase_ev)); // the next phase starts where this one ended
+    HIPCHK(hipEventRecord(h->phase_ev, h->stream));
     return 0;
 }
 extern "C" int pfslam_set_timing(pfslam_handle *h, int enable)
@@ -831,17 +707,21 @@ extern "C" int pfslam_set_timing(pfslam_handle *h, int enable)
     if (!h) return fail("null handle");
     CHK(flush_timers(h));
     h->timing = enable;
-    h->score_ms = 0.0;
-    h->score_launches = 0;
+    for (int k = 0; k < PF_TIMER_SLOTS; k++) {
+        h->timer_ms[k] = 0.0;
+        h->timer_count[k] = 0;
+    }
     return 0;
 }
-extern "C" int pfslam_get_timers(pfslam_handle *h, double out[4])
+extern "C" int pfslam_get_timers(pfslam_handle *h, double out[12])
 {
     if (!h || !out) return fail("pfslam_get_timers: bad argument");
     CHK(flush_timers(h));
-    out[0] = h->score_ms;
-    out[1] = (double)h->score_launches;
-    out[2] = out[3] = 0.0;
+    for (int k = 0; k < PF_TIMER_SLOTS; k++) {
+        out[2 * k] = h->timer_ms[k];
+        out[2 * k + 1] = (double)h->timer_count[k];
+    }
+    out[10] = out[11] = 0.0;
     return 0;
 }
 
@@ -852,74 +732,21 @@ extern "C" int pfslam_set_variant(pfslam_handle *h, int variant)
     return 0;
 }
 
-// BFS image of the top of the tree for the LDS-staged score kernel.  Staged levels must be complete and have
-// split axis = level % 3 (true for every tree KDTree::Create/InsertNode can produce once it has enough nodes).
-static int refresh_top_exit(pfslam_handle *h)
-{
-    if (h->top_levels <= 0) return 0;
-    const int L = h->top_levels, first_last = (1 << (L - 1)) - 1, n_last = 1 << (L - 1);
-    std::vector<int> ex((size_t)2 * n_last);
-    for (int k = 0; k < n_last; k++) {
-        const pfslam_node &nd = h->h_nodes[h->h_top_orig[first_last + k]];
-        ex[2 * k] = nd.left;
-        ex[2 * k + 1] = nd.right;
-    }
-    HIPCHK(hipMemcpyAsync(h->top_exit, ex.data(), ex.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
-static int build_top_image(pfslam_handle *h)
-{
-    h->top_levels = 0;
-    const int n = h->kd_size;
-    if (!h->planar || n <= 0) return 0;
-    std::vector<int> orig;
-    orig.reserve(PF_TOP_SLOTS);
-    orig.push_back(0);
-    int levels = 0;
-    for (int lvl = 0; lvl < PF_TOP_LEVELS; lvl++) {
-        const int first = (1 << lvl) - 1, count = 1 << lvl;
-        bool ok = true;
-        for (int k = 0; k < count && ok; k++) ok = h->h_nodes[orig[first + k]].axis == lvl % 3;
-        if (!ok) break;
-        levels = lvl + 1;
-        if (lvl + 1 == PF_TOP_LEVELS) break;
-        bool complete = true; // next level must be complete to be staged too
-        for (int k = 0; k < count && complete; k++) {
-            const pfslam_node &nd = h->h_nodes[orig[first + k]];
-            complete = nd.left >= 0 && nd.right >= 0;
-        }
-        if (!complete) break;
-        for (int k = 0; k < count; k++) {
-            const pfslam_node &nd = h->h_nodes[orig[first + k]];
-            orig.push_back(nd.left);
-            orig.push_back(nd.right);
-        }
-    }
-    if (levels < 6) return 0; // tiny maps: not worth staging
-    const int nslots = (1 << levels) - 1;
-    std::vector<float2> pos((size_t)nslots);
-    for (int k = 0; k < nslots; k++) pos[k] = make_float2(h->h_nodes[orig[k]].x, h->h_nodes[orig[k]].y);
-    orig.resize((size_t)nslots);
-    h->h_top_orig = orig;
-    h->top_levels = levels;
-    HIPCHK(hipMemcpyAsync(h->top_pos, pos.data(), (size_t)nslots * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->top_orig, orig.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return refresh_top_exit(h);
-}
-
-// upload a tree: host mirror + split device layout
+// upload a tree: host mirror + split device layout.  Everything is validated and packed BEFORE the handle changes, so a
+// refused map leaves the previous one intact (host mirror, size and device arrays stay consistent).
 static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
 {
     if (n > h->kd_cap) return fail("map larger than kd_capacity");
-    h->h_nodes.assign(nodes, nodes + n);
-    h->kd_size = n;
-    if (n == 0) return 0;
+    if (n == 0) {
+        h->h_nodes.clear();
+        h->kd_size = 0;
+        return 0;
+    }
     std::vector<uint4> hot(n);
     std::vector<int> par(n);
     std::vector<float> z(n), w(n);
     int planar = 1;
+    bool integral = true;
     for (int i = 0; i < n; i++) {
         const pfslam_node &nd = nodes[i];
         if (nd.axis < 0 || nd.axis > 2 || nd.left < -1 || nd.left >= n || nd.right < -1 || nd.right >= n ||
@@ -929,19 +756,23 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
         z[i] = nd.z;
         w[i] = nd.w;
         if (nd.z != 0.0f) planar = 0;
+        // |w| <= 2^13 keeps every partial sum of 1081 weights below 2^24, i.e. exact in any order
+        if (!(nd.w == (float)(int)nd.w && fabsf(nd.w) <= 8192.0f)) integral = false;
     }
     for (int i = 0; i < n; i++) {
         const pfslam_node &nd = nodes[i];
         hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right, planar != 0);
         if (planar && nd.axis == 2) memcpy(&z[i], &nd.left, 4); // true left child of a planar z-level node
     }
-    h->planar = planar;
-    CHK(build_top_image(h));
     HIPCHK(hipMemcpyAsync(h->hot, hot.data(), (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kw, w.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->h_nodes.assign(nodes, nodes + n);
+    h->kd_size = n;
+    h->planar = planar;
+    h->integral_w = integral;
     return 0;
 }
 
@@ -1064,6 +895,10 @@ static int score_chunks(const pfslam_handle *h)
     static const int target = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 131072;
     int chunks = (target + groups - 1) / groups;
     chunks = std::max(1, std::min(chunks, h->nb)); // small particle counts go down to one beam per wave
+    // Beam-chunk partials added afterwards equal the reference's sequential beam-order float sum only when every term is an
+    // integer (any map the SLAM step builds: 0 / -100 initial, -1 / +4 steps, clamp +-113).  A map uploaded through
+    // pfslam_set_map with other weights is scored in one chunk: slower, but kernEvaluateParticlesKD's own summation order.
+    if (!h->integral_w) chunks = 1;
     return chunks;
 }
 
@@ -1074,7 +909,8 @@ static int launch_stats_reset(pfslam_handle *h, hipStream_t st);
 
 // fuse_minmax: the frame loops want the packed min/max keys of this shard right away; the reduce kernel then produces them
 // too (one launch less on the chain).  Needs more than one beam chunk, which every launch below ~8 M particles has.
-static int launch_score(pfslam_handle *h, bool fuse_minmax = false)
+// census: run the counting instantiation of the score kernel instead (same launch shape, same results).
+static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus *census = nullptr)
 {
     if (h->kd_size <= 0) return fail("pfslam_score_kd: no map loaded");
     const int chunks = score_chunks(h);
@@ -1102,7 +938,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false)
                            h->cells + 2 * PF_CELLS, h->order2);
         HIPCHK(hipGetLastError());
         order = h->order2;
-    } else if (h->variant != 1 && h->n > 64) { // large N, or variant 6 (A/B): 30-bit Hilbert keys + hipCUB sort; variant 1 = identity order
+    } else if (h->variant != 1 && h->n > 64) { // large N, or variant 6 (A/B): 30-bit Hilbert keys + radix sort; variant 1 = identity order
         hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose,
                            h->mkey, h->order);
         size_t tb = h->sort_tmp_bytes;
@@ -1110,46 +946,32 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false)
             return fail("particle order sort failed");
         order = h->order2;
     }
-    dim3 grid((h->n + 255) / 256, used);
     const int direct = used > 1 ? 0 : 1;
-    std::pair<hipEvent_t, hipEvent_t> tp{nullptr, nullptr};
-    if (h->timing) {
-        CHK(timer_pair(h, tp));
-        HIPCHK(hipEventRecord(tp.first, h->stream));
+    hipEvent_t t_a = nullptr, t_b = nullptr;
+    if (h->timing && !census) {
+        CHK(timer_event(h, &t_a));
+        CHK(timer_event(h, &t_b));
+        HIPCHK(hipEventRecord(t_a, h->stream));
     }
-    // variant 3 = LDS-staged tree top.  Measured on MI355X (100 k particles, 100 k-point map): 2.48 ms vs 2.41 ms for the plain
-    // kernel although it issues 25 % fewer gathers -- the TA path, VALU issue and the 8-wave latency budget saturate together
-    // (DESIGN.md section 4); a persistent-block version was slower still (3.5 ms).  Variants 3-5 are kept for A/B only.
-    const bool use_lds = h->planar && h->top_levels > 0 && h->variant == 3;
-    if (use_lds && h->top_exit_stale) {
-        CHK(refresh_top_exit(h));
-        h->top_exit_stale = false;
-    }
-    if (use_lds)
-        hipLaunchKernelGGL(k_score_kd_lds, dim3((h->n + 1023) / 1024, used), dim3(1024), 0, h->stream, h->x, h->y, h->th, h->n,
-                           h->scan, h->nb, bpc, kd_view(h), h->top_pos, h->top_orig, h->top_exit, h->top_levels, order, direct, out);
-    else if (h->planar && h->variant == 5)
-        hipLaunchKernelGGL(k_score_kd_batched, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                           kd_view(h), order, direct, out);
-    else if (h->planar && h->variant == 4)
-        hipLaunchKernelGGL(k_score_kd_x2, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                           kd_view(h), order, direct, out);
-    else if (h->planar) {
-        // PFSLAM_DBG_LDS: pad the launch with dynamic LDS to cap the occupancy (bound-ness experiments only)
-        static const int dbg_lds = getenv("PFSLAM_DBG_LDS") ? atoi(getenv("PFSLAM_DBG_LDS")) : 0;
-        // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
-        // (2.387 vs 2.400 ms with 256-thread groups)
-        const int blk = 64;
-        hipLaunchKernelGGL(k_score_kd<true>, dim3((h->n + blk - 1) / blk, used), dim3(blk), dbg_lds, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
-                           bpc, kd_view(h), order, direct, out);
-    }
+    // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
+    // (2.387 vs 2.400 ms with 256-thread groups)
+    const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
+    if (h->planar && census)
+        hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                           kd_view(h), order, direct, out, census);
+    else if (census)
+        hipLaunchKernelGGL((k_score_kd<false, true>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                           kd_view(h), order, direct, out, census);
+    else if (h->planar)
+        hipLaunchKernelGGL((k_score_kd<true, false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                           kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
     else
-        hipLaunchKernelGGL(k_score_kd<false>, grid, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb,
-                           bpc, kd_view(h), order, direct, out);
+        hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                           kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
     HIPCHK(hipGetLastError());
-    if (h->timing) {
-        HIPCHK(hipEventRecord(tp.second, h->stream));
-        h->ev_pending.push_back(tp);
+    if (t_a) {
+        HIPCHK(hipEventRecord(t_b, h->stream));
+        h->ev_pending.push_back(pfslam_handle::TimedSpan{t_a, t_b, PF_T_SCORE});
     }
     if (fuse_minmax) {
         if (h->icp_forked) CHK(join_icp(h)); // the aux stream reset the keys
@@ -1172,6 +994,24 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false)
             HIPCHK(hipGetLastError());
         }
     }
+    return 0;
+}
+
+// What one launch of the score kernel issues on the handle's current particles, scan and map: the counting instantiation
+// of the same kernel (same launch shape and lane order) -> out[0] wave-level trips of the descent loop (= wave-level 16-byte
+// gathers of node records), out[1] active lanes in them (= node visits), out[2] wave-level parent-hyperplane tests (each one
+// 4-byte and one 16-byte wave gather), out[3] lanes in them.  fit[] is recomputed (identical values).
+extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[4])
+{
+    if (!h || !out) return fail("pfslam_score_census: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->d_census) CHK(dalloc(&h->d_census, 1));
+    HIPCHK(hipMemsetAsync(h->d_census, 0, sizeof(pf::KdCensus), h->stream));
+    CHK(launch_score(h, false, h->d_census));
+    pf::KdCensus c;
+    HIPCHK(hipMemcpyAsync(&c, h->d_census, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out[0] = c.trips; out[1] = c.lanes; out[2] = c.tests; out[3] = c.test_lanes;
     return 0;
 }
 
@@ -1199,6 +1039,69 @@ extern "C" int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_l
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_per_launch = ms / iters;
+    return 0;
+}
+
+// ---- measurement support: the chip's wave-gather rate, measured live (the roofline the score kernel is priced against) ----
+// Dependent-free wave-level 16-byte gathers from a 2 MB table (cache resident, like the hot map records), 8 waves per SIMD, 8
+// gathers in flight per lane; every lane of a wave reads the same pseudo-random record (the cheapest case for the L1: what is
+// measured is the address / data path of the texture addresser, 4 lanes per clock for 64-bit and wider loads).
+__global__ __launch_bounds__(256) void k_ubench_gather(const unsigned *__restrict__ table, int n_rec, int iters, unsigned *__restrict__ out)
+{
+    const pf::kd_rsrc_t r = pf::kd_rsrc(table);
+    const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+    unsigned state = (gid >> 6) * 2654435761u + 12345u, acc = 0;
+    for (int it = 0; it < iters; it++) {
+        int idx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            state = state * 1664525u + 1013904223u;
+            idx[k] = (int)((state >> 8) & (unsigned)(n_rec - 1));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint4 v = pf::kd_load_hot(r, idx[k]);
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    out[gid] = acc;
+}
+// out[0] = wave-level 16-byte gathers per second over the whole chip, out[1] = compute units, out[2] = nominal clock (GHz),
+// out[3] = cycles per wave gather per CU at the nominal clock
+extern "C" int pfslam_ubench_gather(pfslam_handle *h, double out[4])
+{
+    if (!h || !out) return fail("pfslam_ubench_gather: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
+    const int cus = prop.multiProcessorCount, n_rec = 131072, iters = 400;
+    const int blocks = cus * 8 * 4; // 8 blocks of 4 waves per CU = 8 waves per SIMD, 4 rounds
+    unsigned *table = nullptr, *sink = nullptr;
+    CHK(dalloc(&table, (size_t)n_rec * 4));
+    CHK(dalloc(&sink, (size_t)blocks * 256));
+    std::vector<unsigned> init((size_t)n_rec * 4);
+    for (size_t i = 0; i < init.size(); i++) init[i] = (unsigned)(i * 2654435761u);
+    HIPCHK(hipMemcpyAsync(table, init.data(), init.size() * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, h->stream, table, n_rec, 10, sink);
+    float best = 0.0f;
+    for (int rep = 0; rep < 3; rep++) { // best of three
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, h->stream, table, n_rec, iters, sink);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipEventSynchronize(h->ev1));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        if (rep == 0 || ms < best) best = ms;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFree(table));
+    HIPCHK(hipFree(sink));
+    const double wave_gathers = (double)blocks * 4 * iters * 8;
+    const double ghz = prop.clockRate * 1e-6;
+    out[0] = wave_gathers / (best * 1e-3);
+    out[1] = cus;
+    out[2] = ghz;
+    out[3] = best * 1e-3 * ghz * 1e9 * cus / wave_gathers;
     return 0;
 }
 
@@ -1244,22 +1147,6 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(d_in));
     HIPCHK(hipFree(d_out));
-    return 0;
-}
-
-// experiment support: loop-trip census of the traversal (all zeros unless built with -DPF_EXP_COUNT)
-extern "C" int pfslam_debug_census(pfslam_handle *h, unsigned long long out[4], int reset)
-{
-    if (!h || !out) return fail("pfslam_debug_census: bad argument");
-    memset(out, 0, 32);
-#ifdef PF_EXP_COUNT
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_trip_census), 32));
-    if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pf::g_trip_census), z, 32));
-    }
-#endif
     return 0;
 }
 

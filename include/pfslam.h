@@ -62,7 +62,8 @@ typedef struct pfslam_config {
     float map_res_x, map_res_y;     /* Patch.resolution (0.025).  int(scale / res) must be the same in x and y: the
                                      * reference indexes cell (x, y) as x * dim.x + y (kernel.cu:120, 539, 1438), which is
                                      * only well defined on a square grid; pfslam_create refuses anything else */
-    int32_t kd_capacity;   /* KD_MAX_SIZE (kernel.cu:77); nodes */
+    int32_t kd_capacity;   /* KD_MAX_SIZE (kernel.cu:77); nodes, at most 2^27 - 1.  A frame whose new walls do not fit makes
+                            * pfslam_step fail ("kd_capacity exhausted") -- the reference has no bound check at all */
     int32_t device;        /* HIP device ordinal */
     int32_t strict_host_mirror; /* 1 = reproduce the half-array weight read-back of kernel.cu:1341 (H11) */
     int32_t free_upload_bug;    /* 1 = reproduce kernel.cu:1475 (free list tail zero) (H6); 0 = full list */
@@ -76,7 +77,9 @@ typedef struct pfslam_config {
 
 typedef struct pfslam_handle pfslam_handle;
 
-/* defaults of the reference: 1081 beams, 40x40 m @ 0.025 m, strict parity flags on */
+/* defaults of the reference: 1000 particles, 1081 beams, 40x40 m @ 0.025 m, kd_capacity = KD_MAX_SIZE = 10 M nodes,
+ * balance_period 100, strict_host_mirror = 1 (H11 reproduced), free_upload_bug = 0 (H6 NOT reproduced: the full free list is
+ * applied -- the reference's truncated upload reads uninitialised device memory, which has no defined result to match) */
 void pfslam_default_config(pfslam_config *cfg);
 int pfslam_create(const pfslam_config *cfg, pfslam_handle **out);
 int pfslam_destroy(pfslam_handle *h);
@@ -173,29 +176,30 @@ int pfslam_shard_finish(pfslam_handle *h, int frame, int *resampled, float *neff
  *        10 global w, 11 global x, 12 global y, 13 global theta (global_n x f32 each; alias 5,2,3,4 when unsharded) */
 int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
 
-/* ---- bench support: time `iters` back-to-back launches of the score kernel with HIP events on the
- * handle's stream; returns the average milliseconds per launch ---- */
+/* ---- measurement support ----
+ * pfslam_time_score_kd: `iters` back-to-back scoring passes (lane order + scan-match kernel + partial-sum reduce, i.e. all of
+ *   pfslam_score_kd's device work) between two HIP events on the handle's stream; average milliseconds per pass.
+ * pfslam_set_timing: 0 = off; 1 = HIP events on the handle's stream bracket every launch of the scan-match kernel (only that
+ *   kernel) inside pfslam_step / pfslam_shard_begin; 2 = additionally the four phases the reference times per frame
+ *   (kernel.cu:1727-1760: motion, measurement incl. ICP, map update incl. its host part, resample).  Resets the accumulators.
+ * pfslam_get_timers -> out[2k] = total ms, out[2k+1] = count, k = 0 scan-match kernel, 1 motion, 2 measurement, 3 map,
+ *   4 resample; out[10..11] reserved (0).
+ * pfslam_score_census: what one scoring launch on the handle's CURRENT particles, scan and map issues, counted by a counting
+ *   instantiation of the same kernel with the same launch shape and lane order: out[0] wave-level trips of the descent loop
+ *   (= wave-level 16-byte gathers of node records), out[1] active lanes in them (= node visits), out[2] wave-level
+ *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them.
+ * pfslam_set_variant: lane order of the scoring pass (results are bit-identical; A/B measurements): 0 = default (lanes along a
+ *   Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys above), 6 = always the
+ *   sorted 30-bit keys, 1 = identity order. */
 int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
-/* live timing of the scan-match kernel inside pfslam_step: HIP events on the handle's stream bracket every
- * launch; pfslam_get_timers -> [total ms, launches, 0, 0].  pfslam_set_timing also resets the accumulators. */
 int pfslam_set_timing(pfslam_handle *h, int enable);
-int pfslam_get_timers(pfslam_handle *h, double out[4]);
-/* scoring kernel variant (all bit-identical; for A/B measurements): 0 = default (lanes ordered along a Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys
- * above), 6 = always the sorted 30-bit keys, 1 = identity lane
- * order, 3 = default + LDS-staged tree top, 4 = default + two interleaved beams per lane, 5 = default + re-descents of 4 beams batched
- * per lane (3-5 are measured-and-slower experiments kept for A/B) */
+int pfslam_get_timers(pfslam_handle *h, double out[12]);
+int pfslam_score_census(pfslam_handle *h, unsigned long long out[4]);
+/* the chip's wave-level 16-byte gather rate measured live by a micro-benchmark (cache-resident 2 MB table, 8 waves per SIMD):
+ * out[0] = wave gathers per second (whole chip), out[1] = compute units, out[2] = nominal clock in GHz, out[3] = cycles per
+ * wave gather per CU at the nominal clock.  The scan-match kernel issues one such gather per node visit of a wave. */
+int pfslam_ubench_gather(pfslam_handle *h, double out[4]);
 int pfslam_set_variant(pfslam_handle *h, int variant);
-
-/* ---- debug: evaluate the bit-reproducible math specification (pf_math.h) on the device.
- * which: 0 sincos (out: n x {sin, cos}), 1 erfcinv, 2 asin, 3 rsqrt, 4 sqrt_rn, 5 x / 0.025f ---- */
-int pfslam_debug_math(pfslam_handle *h, int which, const float *in_host, int n, float *out_host);
-
-/* experiment support: [wave trips of the descent loop, active lanes summed over them, wave-level parent tests, lanes in
- * them] since the last reset; all zero unless the library is built with -DPF_EXP_COUNT */
-int pfslam_debug_census(pfslam_handle *h, unsigned long long out[4], int reset);
-/* experiment hook: the launch-bound chain of pfslam_step_grid as plain launches vs a captured hipGraph;
- * out_ms[0] = direct, out_ms[1] = graph replay, per chain (tools/graph_probe.py) */
-int pfslam_debug_graph_probe(pfslam_handle *h, int iters, float out_ms[2]);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
 int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);

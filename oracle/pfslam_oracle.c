@@ -1376,6 +1376,99 @@ void orc_slam_step_grid(orc_slam *s, int frame, const float *scan)
     memcpy(&s->trace[5], &neff, 4);
 }
 
+/* The reference's own CPU path of the 2-D frame loop: the `GPU_* == 0` branches (H7 semantics, which DIFFER from the GPU
+ * branches above and are therefore a timing baseline for BASELINE configs[0], not the parity target):
+ *   PFMotionUpdate      kernel.cu:414-417   ParticleAddNoise on the host array, same per-particle engines
+ *   PFMeasurementUpdate kernel.cu:340-369   strict `>` / `<` scan for best / worst, w *= (float)(fit - worst) / (float)(best - worst)
+ *   PFUpdateMap         kernel.cu:578-620   no 20 m reject; a ray is traced only if its end cell is inside the map; free cells
+ *                                           get -1 once per cell (mask), wall cells +4 once per BEAM; clamp +-113
+ *   PFResample          kernel.cu:463-508   sequential sums, sequential prefix sum, ONE engine seeded (Neff, frame, 0) drawing N
+ *                                           numbers, in-place sequential copies (later picks see earlier overwrites)
+ * There is one particle array only (the host one). */
+void orc_slam_step_grid_cpu(orc_slam *s, int frame, const float *scan)
+{
+    const int n = s->cfg.n_particles, nb = s->cfg.n_beams, dimx = s->dimx, dimy = s->dimy;
+    const orc_patch *pa = &s->cfg.patch;
+    orc_particle *p = s->host;
+    orc_slam_grid_alloc(s);
+    memset(s->trace, 0, sizeof(s->trace));
+    orc_add_noise(p, n, frame, 0); /* kernel.cu:414-417 */
+    /* PFMeasurementUpdate, CPU branch */
+    int best = -128 * nb, worst = 128 * nb, iBest = 0;
+    orc_score_grid(s->grid, dimx, dimy, pa, p, n, scan, nb, s->fit_i); /* EvaluateParticle is __host__ __device__ */
+    for (int i = 0; i < n; i++) {
+        if (s->fit_i[i] > best) {
+            best = s->fit_i[i];
+            iBest = i;
+        }
+        if (s->fit_i[i] < worst) worst = s->fit_i[i];
+    }
+    if ((best - worst) > 0)
+        for (int i = 0; i < n; i++) {
+            float f = (float)(s->fit_i[i] - worst) / (float)(best - worst);
+            p[i].w *= f;
+        }
+    s->robot[0] = p[iBest].x;
+    s->robot[1] = p[iBest].y;
+    s->robot[2] = p[iBest].theta;
+    s->trace[0] = iBest;
+    /* PFUpdateMap, CPU branch */
+    {
+        const int cx = (int)roundf(0.5f * dimx + s->robot[0] / pa->res_x + pa->res_x / 2);
+        const int cy = (int)roundf(0.5f * dimy + s->robot[1] / pa->res_y + pa->res_y / 2);
+        const size_t M = (size_t)dimx * dimy;
+        const long clamp_val = (1 << (sizeof(int8_t) * 8 - 1)) - 15;
+        memset(s->free_mask, 0, M);
+        float *wx = s->wall_pts, *wy = s->wall_pts + nb; /* glm::vec2 walls[LIDAR_SIZE] */
+        for (int i = 0; i < nb; i++) {
+            orc_clean_lidar_scan(i, scan[i], s->robot[2], &wx[i], &wy[i]);
+            wx[i] = roundf(wx[i] / pa->res_x);
+            wy[i] = roundf(wy[i] / pa->res_y);
+            wx[i] += (float)cx;
+            wy[i] += (float)cy;
+            if (wx[i] >= 0 && wx[i] < dimx && wy[i] >= 0 && wy[i] < dimy)
+                orc_trace_ray(cx, cy, (int)wx[i], (int)wy[i], dimx, dimy, s->free_mask);
+        }
+        for (size_t idx = 0; idx < M; idx++)
+            if (s->free_mask[idx]) {
+                long v = s->grid[idx] + ORC_FREE_WEIGHT;
+                s->grid[idx] = (int8_t)((v < -clamp_val) ? -clamp_val : (v > clamp_val) ? clamp_val : v);
+            }
+        for (int i = 0; i < nb; i++)
+            if (wx[i] >= 0 && wx[i] < dimx && wy[i] >= 0 && wy[i] < dimy) {
+                int idx = (int)wx[i] * dimx + (int)wy[i];
+                long v = s->grid[idx] + ORC_OCCUPIED_WEIGHT;
+                s->grid[idx] = (int8_t)((v < -clamp_val) ? -clamp_val : (v > clamp_val) ? clamp_val : v);
+            }
+    }
+    /* PFResample, CPU branch */
+    float r = 0, r2 = 0;
+    for (int i = 0; i < n; i++) {
+        r += p[i].w;
+        r2 += (p[i].w) * (p[i].w);
+    }
+    float Neff = r * r / r2;
+    int did = 0;
+    if (Neff < ORC_EFFECTIVE_PARTICLES * n) {
+        float *weightsum = s->fit; /* float weightsum[PARTICLE_COUNT] */
+        weightsum[0] = p[0].w;
+        for (int i = 1; i < n; i++) weightsum[i] = weightsum[i - 1] + p[i].w;
+        uint32_t gen = orc_engine_seed((int)Neff, frame, 0);
+        for (int i = 0; i < n; i++) {
+            int idx = 0;
+            float rnd = orc_uniform_real(&gen, 0.0f, weightsum[n - 1]);
+            while (idx < n && rnd > weightsum[idx]) idx++;
+            if (idx >= n) idx = n - 1; /* the reference would read particles[N] */
+            p[i] = p[idx];
+            p[i].w = 1.0f;
+        }
+        did = 1;
+    }
+    memcpy(s->dev, p, sizeof(orc_particle) * (size_t)n); /* "push particles to GPU to draw" */
+    s->trace[1] = did;
+    memcpy(&s->trace[5], &Neff, 4);
+}
+
 void orc_slam_set_particles(orc_slam *s, const orc_particle *p)
 {
     memcpy(s->dev, p, sizeof(orc_particle) * (size_t)s->cfg.n_particles);

@@ -168,6 +168,8 @@ void orc_slam_set_map(orc_slam *s, const orc_node *tree, int n);
 void orc_slam_step(orc_slam *s, int frame, const float *scan);
 /* 2-D grid variant (stages kernel.cu:400-418, 307-339, 551-577, 447-511 in the frame loop of 1702-1762) */
 void orc_slam_step_grid(orc_slam *s, int frame, const float *scan);
+/* the reference's CPU branches of the same loop (GPU_* == 0; H7 semantics; timing baseline for BASELINE configs[0]) */
+void orc_slam_step_grid_cpu(orc_slam *s, int frame, const float *scan);
 void orc_slam_set_grid(orc_slam *s, const int8_t *grid);
 const int8_t *orc_slam_grid(orc_slam *s);
 void orc_slam_set_particles(orc_slam *s, const orc_particle *p); /* device array and host mirror */

@@ -13,7 +13,7 @@ os.environ.setdefault("ORC_THREADS", str(min(64, os.cpu_count() or 1)))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-cases = frames_total = 0
+cases = frames_total = refused = 0
 
 
 def bits(a):
@@ -66,8 +66,10 @@ while time.time() < t_end:
             else:
                 o.step(f, scan); h.step(f, scan)
         except pkg.PfSlamError as e:
-            # the only legitimate refusal: map capacity exhausted (the oracle has no such limit below its own cap)
-            if "capacity" in str(e) or "kd_capacity" in str(e):
+            # the only legitimate refusal: map capacity exhausted -- the product fails loudly where the oracle (like the
+            # reference, which has no bound check at all) just stops inserting; the case ends there
+            if "kd_capacity exhausted" in str(e) or "kd_capacity too small" in str(e):
+                ok = False
                 break
             print("UNEXPECTED ERROR", desc, f, e); sys.exit(2)
         to, tg = o.trace(), h.trace()
@@ -75,6 +77,10 @@ while time.time() < t_end:
         if not same or not (bits(h.pose) == bits(o.pose)).all():
             print("DIVERGED", desc, "frame", f, tg, to, h.pose, o.pose); sys.exit(1)
         frames_total += 1
+    if not ok:
+        h.close(); o.close()
+        refused += 1
+        continue
     if grid_mode:
         if not (h.grid() == o.grid).all():
             print("DIVERGED grid", desc); sys.exit(1)
@@ -87,4 +93,4 @@ while time.time() < t_end:
             print("DIVERGED particles", fld, desc); sys.exit(1)
     h.close(); o.close()
     cases += 1
-print("fuzz ok: %d cases, %d frames" % (cases, frames_total))
+print("fuzz ok: %d cases, %d frames (%d cases ended by a loud kd_capacity refusal)" % (cases, frames_total, refused))

@@ -100,6 +100,7 @@ def lib():
     L.orc_slam_set_map.restype = None; L.orc_slam_set_map.argtypes = [vp, vp, i32]
     L.orc_slam_step.restype = None; L.orc_slam_step.argtypes = [vp, i32, vp]
     L.orc_slam_step_grid.restype = None; L.orc_slam_step_grid.argtypes = [vp, i32, vp]
+    L.orc_slam_step_grid_cpu.restype = None; L.orc_slam_step_grid_cpu.argtypes = [vp, i32, vp]
     L.orc_slam_set_grid.restype = None; L.orc_slam_set_grid.argtypes = [vp, vp]
     L.orc_slam_grid.restype = vp; L.orc_slam_grid.argtypes = [vp]
     L.orc_slam_set_particles.restype = None; L.orc_slam_set_particles.argtypes = [vp, vp]
@@ -249,6 +250,11 @@ class Slam:
     def step_grid(self, frame, scan):
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         lib().orc_slam_step_grid(self.h, frame, P(scan))
+
+    def step_grid_cpu(self, frame, scan):
+        """The reference's CPU branches of the 2-D frame loop (kernel.cu:340-369, 487-508, 578-620; H7)."""
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        lib().orc_slam_step_grid_cpu(self.h, frame, P(scan))
 
     def set_grid(self, grid):
         grid = np.ascontiguousarray(grid, dtype=np.int8)

@@ -1,0 +1,132 @@
+"""BASELINE configs[3]: 1 M particles sharded over 8 GPUs against a 500 000-point map -- per GPU that is 125 000
+particles of the global array x 1081 beams x a depth-19 KD tree (reference: KD_MAX_SIZE kernel.cu:77-79, scoring
+kernel.cu:1301-1308, per-thread RNG keyed by the particle index kernel.cu:375-397).  One MI355X can only hold one
+shard's worth of work at a time, so the tests run shards of the 1 M-particle job on the one GPU of the box:
+  * a shard's dispersion + scores equal the oracle's on sampled particles (the oracle is seeded with GLOBAL indices),
+  * scores do not depend on which lane / slot scores a particle (permutation invariance at full size),
+  * whole-step replays on the 500 k-point map equal the (threaded-scoring) oracle bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+MAP_POINTS = 500000
+SHARD = 125000
+GLOBAL = 1000000
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if pkg.device_count() <= 0:
+        pytest.fail("no HIP device: the -m gpu tests need an MI355X (there is no CPU fallback)")
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def world500k(gpu):
+    pts, segs = gpu.synth.make_map_points(MAP_POINTS, seed=1)
+    tree = gpu.kd_create(pts)
+    assert len(tree) == MAP_POINTS
+    scan = gpu.synth.make_scan(segs, (0.05, -0.03, 0.02), seed=2)
+    return {"pts": pts, "segs": segs, "tree": tree, "scan": scan}
+
+
+def _sample_idx(n, k=320, seed=7):
+    rng = np.random.RandomState(seed)
+    idx = np.unique(np.concatenate([[0, 1, 63, 64, n // 2, n - 65, n - 64, n - 1], rng.randint(0, n, k)]))
+    return idx.astype(np.int64)
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_cfg3_shard_dispersion_and_score_match_oracle(gpu, world500k, rank):
+    """Shard `rank` of the 8 x 125 000 global particles: three dispersion steps (global RNG indices) and one scoring
+    pass on the 500 k-point map; poses and scores of >= 256 sampled particles are bit-identical to the oracle."""
+    w = world500k
+    goff = rank * SHARD
+    h = gpu.PfSlam(SHARD, kd_capacity=MAP_POINTS + (1 << 16), global_offset=goff, global_n=GLOBAL)
+    h.set_map(w["tree"])
+    p0 = O.make_particles(SHARD, 0.05, -0.03, 0.02)
+    h.set_particles(p0)
+    h.set_scan(w["scan"])
+    for f in (1, 2, 3):
+        h.motion_update(f)
+    fit = h.score_kd()
+    got = h.particles()
+    idx = _sample_idx(SHARD)
+    assert len(idx) >= 256
+    # the oracle disperses particle i of the shard with RNG index goff + i: one call per sampled particle
+    want_p = O.make_particles(len(idx), 0.05, -0.03, 0.02)
+    for k, i in enumerate(idx):
+        one = want_p[k:k + 1]
+        for f in (1, 2, 3):
+            O.add_noise(one, f, idx0=goff + int(i))
+    for fld in ("x", "y", "theta"):
+        assert (bits(got[fld][idx]) == bits(want_p[fld])).all(), fld
+    want, visits, valid = O.score_kd(w["tree"], want_p, w["scan"], stats=True)
+    assert (bits(fit[idx]) == bits(want)).all()
+    assert valid > 900 * len(idx) and visits / valid > 15  # a real depth-19 traversal, not a degenerate scan
+    h.close()
+
+
+def test_cfg3_score_is_permutation_invariant(gpu, world500k):
+    """125 000 particles x 500 k-point map: scoring a shuffled copy of the particle array gives the shuffled scores
+    (the lane order, beam chunking and partial-sum reduce cannot leak into the result)."""
+    w = world500k
+    h = gpu.PfSlam(SHARD, kd_capacity=MAP_POINTS + (1 << 16))
+    h.set_map(w["tree"])
+    p = O.make_particles(SHARD, 0.05, -0.03, 0.02)
+    for f in (1, 2, 3, 4):
+        O.add_noise(p, f)
+    h.set_particles(p)
+    h.set_scan(w["scan"])
+    fit = h.score_kd()
+    perm = np.random.RandomState(11).permutation(SHARD)
+    h.set_particles(p[perm])
+    fit2 = h.score_kd()
+    assert (bits(fit2) == bits(fit[perm])).all()
+    # and the lane-order variants agree with each other: identity order, counting sort, 30-bit key sort
+    for v in (1, 6):
+        h.set_variant(v)
+        assert (bits(h.score_kd()) == bits(fit2)).all(), v
+    idx = _sample_idx(SHARD, k=256, seed=3)
+    want = O.score_kd(w["tree"], np.ascontiguousarray(p[perm][idx]), w["scan"])
+    assert (bits(fit2[idx]) == bits(want)).all()
+    h.close()
+
+
+@pytest.mark.parametrize("n,nframes", [(20000, 14), (125000, 4)])
+def test_cfg3_step_replay_on_500k_map(gpu, world500k, monkeypatch, n, nframes):
+    """pfslam_step on the 500 k-point map: 20 000 particles x 14 frames (re-balance of the 500 k tree at frame 5
+    included) and a full 125 000-particle shard x 4 frames -- every frame's trace and pose and the final tree and
+    particles bit-identical to the oracle (threaded scoring, same per-particle arithmetic)."""
+    monkeypatch.setenv("ORC_THREADS", str(min(128, len(os.sched_getaffinity(0)))))
+    w = world500k
+    cap = MAP_POINTS + (1 << 16)
+    o = O.Slam(n, kd_capacity=cap)
+    h = gpu.PfSlam(n, kd_capacity=cap)
+    o.set_map(w["tree"]); h.set_map(w["tree"])
+    resampled = inserted = 0
+    first = 1 if nframes > 5 else 6  # the short replay starts past the frame % 100 == 5 re-balance
+    for k in range(nframes):
+        f = first + k
+        scan = gpu.synth.make_scan(w["segs"], (0.004 * k, 0.002 * k, 0.001 * k), seed=500 + k)
+        o.step(f, scan)
+        h.step(f, scan)
+        to, tg = o.trace(), h.trace()
+        assert tg == to, (f, tg, to)
+        assert (bits(h.pose) == bits(o.pose)).all(), f
+        resampled += to["resampled"]; inserted += to["n_insert"]
+    assert inserted > 0
+    assert h.map().tobytes() == o.tree().tobytes()
+    got, want = h.particles(), o.particles()
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[fld]) == bits(want[fld])).all(), fld
+    h.close(); o.close()

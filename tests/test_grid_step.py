@@ -126,3 +126,55 @@ def test_gpu_grid_step_from_a_preset_grid(pkg):
         assert (bits(h.pose) == bits(o.pose)).all()
     assert (h.grid() == o.grid).all()
     h.close(); o.close()
+
+
+def test_oracle_cpu_branch_first_frame_accounting(pkg):
+    """The reference's CPU branches of the 2-D loop (kernel.cu:340-369, 578-620, 487-508; H7), first frame on the flat
+    -100 grid, against an independent numpy accounting: free cells -1 once per cell, wall cells +4 once per BEAM (the
+    GPU branch adds +4 once per cell), no 20 m reject but rays only to end cells inside the map, best = first slot."""
+    frames = _drive(pkg, 3)
+    scan = frames[0][1].copy()
+    scan[10:20] = 29.0          # beyond the GPU branch's 20 m reject, but inside the 40 m map from the origin? no: 29 m > 20 m half-extent
+    scan[500:510] = 19.5        # inside the map
+    n = 50
+    o = O.Slam(n)
+    o.step_grid_cpu(1, scan)
+    t = o.trace()
+    assert t["best"] == 0 and t["resampled"] == 0
+    p = O.make_particles(n)
+    O.add_noise(p, frame=1)
+    robot = np.array([p["x"][0], p["y"][0], p["theta"][0]], np.float32)
+    assert (bits(o.pose) == bits(robot)).all()
+    res = np.float32(0.025)
+    cx = int(np.round(np.float32(800.0) + robot[0] / res + res / np.float32(2)))
+    cy = int(np.round(np.float32(800.0) + robot[1] / res + res / np.float32(2)))
+    hits = np.zeros((1600, 1600), np.int32)
+    free = np.zeros(1600 * 1600, np.uint8)
+    s, c = O.sincosf(((np.float32(-135.0) + np.arange(1081, dtype=np.float32) * np.float32(.25)) * np.float32(np.pi)) / np.float32(180.0) + robot[2])
+    # np.float32(np.pi) == the reference's PI truncated to float
+    traced = 0
+    for j in range(1081):
+        wx = np.float32(np.round(scan[j] * c[j] / res)) + np.float32(cx)
+        wy = np.float32(np.round(scan[j] * s[j] / res)) + np.float32(cy)
+        if 0 <= wx < 1600 and 0 <= wy < 1600:
+            O.lib().orc_trace_ray(cx, cy, int(wx), int(wy), 1600, 1600, O.P(free))
+            hits[int(wx), int(wy)] += 1
+            traced += 1
+    assert 300 < traced < 1081    # beams whose end cell is outside the map (the 29-30 m ones) trace nothing
+    want = np.full((1600, 1600), -100, np.int32) - free.reshape(1600, 1600) + 4 * hits
+    want = np.clip(want, -113, 113).astype(np.int8)
+    assert (o.grid == want).all()
+    assert hits.max() >= 2        # several beams per wall cell: where the two branches differ
+    # the GPU branch on the same input: same free mask semantics inside 20 m, +4 once per cell
+    g = O.Slam(n)
+    g.step_grid(1, scan)
+    diff = (g.grid != o.grid)
+    assert diff.any() and (g.grid[hits >= 2] <= o.grid[hits >= 2]).all()
+    # a few more frames run and resample (sequential in-place copies, one engine)
+    did = 0
+    for f in (2, 3):
+        o.step_grid_cpu(f, frames[f - 1][1])
+        did += o.trace()["resampled"]
+        pp = o.particles()
+        assert np.isfinite(pp["x"]).all() and (pp["w"] >= 0).all()
+    o.close(); g.close()

@@ -1,47 +1,64 @@
 #!/bin/bash
-# tools/profile_round.sh <tag>  -- run ON THE GPU BOX from the repo root (via gpurun).
-# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/prof_<tag>/kt
-# 2. separate PMC passes (FETCH_SIZE, WRITE_SIZE; SQ/TA sets) of the same command -> gpurun_out/prof_<tag>/pmc_*
+# tools/profile_round.sh <tag> [bench.py workload args...]  -- run ON THE GPU BOX from the repo root (via gpurun).
+#   tools/profile_round.sh r02                                          default workload (100 k particles, 100 k-point map)
+#   tools/profile_round.sh r02_cfg3 --particles 125000 --map-points 500000   BASELINE configs[3]'s per-GPU share
+# 1. rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline <args>`  -> gpurun_out/prof_<tag>/kt
+# 2. separate PMC passes (FETCH_SIZE, WRITE_SIZE; SQ / TA sets) of the same command   -> gpurun_out/prof_<tag>/pmc_*
 # 3. summaries -> gpurun_out/prof_<tag>/summary/*.csv|json   (copy the ones to be judged into profiles/)
-TAG=${1:-r01}
+TAG=${1:-r02}; shift
+ARGS="$*"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT/summary
-CMD="python bench.py --no-cpu-baseline"
+CMD="python bench.py --no-cpu-baseline $ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/bench_kt.log 2>&1
 grep '^{' $OUT/bench_kt.log > $OUT/summary/bench_under_kernel_trace.json
-for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum"; do
   N=$(echo $C | cut -d' ' -f1)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -o pmc -- $CMD > $OUT/bench_pmc_$N.log 2>&1
 done
-python - <<PY
-import csv, glob, json, os, collections
+python - "$ARGS" <<PY
+import csv, glob, json, os, collections, sys, re
 out = "$OUT"
+args = sys.argv[1]
+def arg(name, default):
+    m = re.search(name + r"\s+(\d+)", args)
+    return int(m.group(1)) if m else default
+workload = {"particles": arg("--particles", 100000), "map_points": arg("--map-points", 100000),
+            "steps": arg("--steps", 20), "warmup": arg("--warmup", 5)}
 # kernel stats
 for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     with open(out + "/summary/kernel_stats.csv", "w") as g:
         w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
-# per-dispatch durations of the score kernel (warm-up launches listed separately)
+# per-dispatch durations of the score kernel; the census launches (k_score_kd<..., true>) are a different instantiation
+timed_ms = None
 for f in glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True):
-    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if "k_score_kd" in r["Kernel_Name"]]
-    d.sort()
+    rows = [r for r in csv.DictReader(open(f)) if "k_score_kd" in r["Kernel_Name"]]
+    plain = [r for r in rows if re.search(r"k_score_kd<\s*(true|false)\s*,\s*false\s*>", r["Kernel_Name"]) or not re.search(r",\s*true\s*>", r["Kernel_Name"])]
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in plain)
     durs = [x[1] / 1e3 for x in d]
-    json.dump({"kernel": "k_score_kd", "launch_us": durs, "mean_us_all": sum(durs) / len(durs),
-               "note": "first 3 launches are bench.py's untimed warm-up steps"}, open(out + "/summary/score_kd_launches.json", "w"), indent=1)
-# PMC per launch of the score kernel
+    timed = durs[workload["warmup"]:workload["warmup"] + workload["steps"]]
+    timed_ms = sum(timed) / max(len(timed), 1) / 1e3
+    json.dump({"kernel": "k_score_kd", "workload": workload, "launch_us": durs, "mean_us_all": sum(durs) / len(durs),
+               "mean_us_timed": timed_ms * 1e3,
+               "note": "first %d launches are bench.py's untimed warm-up steps; mean_us_timed = the %d timed ones" % (workload["warmup"], workload["steps"])},
+              open(out + "/summary/score_kd_launches.json", "w"), indent=1)
+# PMC per launch of the score kernel (timed instantiation only)
 pm = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_score_kd" in r["Kernel_Name"]:
+        k = r["Kernel_Name"]
+        if "k_score_kd" in k and not re.search(r",\s*true\s*>", k):
             pm[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in pm.items()}
-res = {"kernel": "k_score_kd", "launches_profiled": {k: len(v) for k, v in pm.items()}, "avg_per_launch": avg}
+res = {"kernel": "k_score_kd", "workload": workload, "kernel_ms": timed_ms, "launches_profiled": {k: len(v) for k, v in pm.items()}, "avg_per_launch": avg}
 if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 rocprofv3 reports half the bytes of wide reads (MI355X_MICROARCH.md, HBM)
     res["hbm_bytes_per_launch"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
     res["hbm_bytes_note"] = "(2 x FETCH_SIZE + WRITE_SIZE) KB; the x2 read correction is the guide's and is uncalibrated for 16-B gathers, so this is an upper bound"
+res["kernel_ms_note"] = "mean duration of the timed launches in the --kernel-trace pass of the same command (PMC passes perturb durations)"
 json.dump(res, open(out + "/summary/pmc_score_kd.json", "w"), indent=1)
-print(json.dumps(res)[:600])
+print(json.dumps(res)[:800])
 PY
 ls -la $OUT/summary

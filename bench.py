@@ -244,11 +244,14 @@ def main():
     pts, segs = pkg.synth.make_map_points(a.map_points, seed=1)
     tree = pkg.kd_create(pts)
     long_run = not a.no_cpu_baseline
-    n_frames = a.warmup + a.steps + (130 if long_run else 0)
-    scans = []
-    for f in range(n_frames):
-        pose = (0.002 * f, 0.001 * f, 0.0004 * f)
-        scans.append(pkg.synth.make_scan(segs, pose, seed=2000 + f))
+    # long-run leg: filler up to the next frame % 100 == 6, 100 timed frames, 20 frames for the phase split
+    n_frames = a.warmup + a.steps + (((6 - (FIRST_FRAME + a.warmup + a.steps)) % 100) + 100 + 20 if long_run else 0)
+
+    def one_scan(f):
+        return pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=host_cpu()[0]) as pool:  # numpy releases the GIL in the ray-casting ufuncs
+        scans = list(pool.map(one_scan, range(n_frames)))
 
     cap = a.map_points + (1 << 18)
     if distributed:
@@ -382,9 +385,9 @@ def main():
     if long_run:
         # continue to the next frame % 100 == 6, then time exactly 100 frames: one KDTree::Balance (frame % 100 == 5) inside
         k = a.warmup + a.steps
-        while frame % 100 != 6 and k < n_frames - 100:
+        while frame % 100 != 6:
             eng.step(frame, scans[k]); frame += 1; k += 1
-        if frame % 100 == 6 and k + 100 <= n_frames:
+        if k + 100 <= n_frames:
             dtl = timed(k, 100, frame)
             frame += 100; k += 100
             if out is not None:

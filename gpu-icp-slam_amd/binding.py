@@ -17,7 +17,7 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_map", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_weights", "pfslam_shard_map", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
@@ -35,7 +35,7 @@ class Config(C.Structure):
                 ("kd_capacity", C.c_int32), ("device", C.c_int32),
                 ("strict_host_mirror", C.c_int32), ("free_upload_bug", C.c_int32),
                 ("balance_period", C.c_int32), ("global_offset", C.c_int32), ("global_n", C.c_int32),
-                ("reserved_", C.c_int32 * 3)]
+                ("shard_stride", C.c_int32), ("reserved_", C.c_int32 * 2)]
 
 
 class PfSlamError(RuntimeError):
@@ -94,6 +94,7 @@ def load():
     L.pfslam_shard_begin.argtypes = [vp, i32, vp, vp]
     L.pfslam_shard_finish.argtypes = [vp, i32, vp, vp]
     L.pfslam_shard_map.argtypes = [vp]
+    L.pfslam_shard_weights.argtypes = [vp]
     L.pfslam_get_pose.argtypes = [vp, vp]
     L.pfslam_get_particles.argtypes = [vp, vp, vp]
     L.pfslam_get_map.argtypes = [vp, vp, vp]
@@ -173,7 +174,7 @@ class PfSlam:
     """One handle = one GPU's shard of particles + a replica of the map."""
 
     def __init__(self, n_particles, n_beams=1081, kd_capacity=1 << 20, device=0, strict_host_mirror=1,
-                 free_upload_bug=0, balance_period=100, global_offset=0, global_n=0, map_scale=None, map_res=None):
+                 free_upload_bug=0, balance_period=100, global_offset=0, global_n=0, shard_stride=0, map_scale=None, map_res=None):
         L = load()
         cfg = Config()
         L.pfslam_default_config(C.byref(cfg))
@@ -183,7 +184,7 @@ class PfSlam:
         if map_res is not None:     # (x, y) cell size in metres (default 0.025)
             cfg.map_res_x, cfg.map_res_y = map_res
         cfg.strict_host_mirror, cfg.free_upload_bug, cfg.balance_period = strict_host_mirror, free_upload_bug, balance_period
-        cfg.global_offset, cfg.global_n = global_offset, global_n
+        cfg.global_offset, cfg.global_n, cfg.shard_stride = global_offset, global_n, shard_stride
         self.cfg = cfg
         self.n, self.nb = n_particles, n_beams
         self._h = C.c_void_p()
@@ -369,6 +370,9 @@ class PfSlam:
         seeded = C.c_int(0)
         _chk(self.L.pfslam_shard_begin(self._h, frame, _p(scan), C.byref(seeded)), "pfslam_shard_begin")
         return bool(seeded.value)
+
+    def shard_weights(self):
+        _chk(self.L.pfslam_shard_weights(self._h), "pfslam_shard_weights")
 
     def shard_map(self):
         _chk(self.L.pfslam_shard_map(self._h), "pfslam_shard_map")

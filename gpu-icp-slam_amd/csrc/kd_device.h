@@ -76,13 +76,25 @@ __device__ uint4 kd_load_hot(kd_rsrc_t r, int idx);
 __device__ int kd_load_i32(kd_rsrc_t r, int idx);
 #endif
 
-// one wave-level event of the census: the first active lane adds (1, active lanes)
-__device__ __forceinline__ void census_add(unsigned long long *ev, unsigned long long *lanes)
+// Per-lane census counters (registers): a wave-level event is booked on its first active lane, every active lane books
+// itself; census_flush adds a wave's totals to the global record once, at the end of the kernel.
+struct KdCensusLocal { unsigned trips, lanes, tests, test_lanes; };
+__device__ __forceinline__ void census_add(unsigned &ev, unsigned &lanes)
 {
     const unsigned long long ex = __builtin_amdgcn_read_exec();
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
-        atomicAdd(ev, 1ull);
-        atomicAdd(lanes, (unsigned long long)__popcll(ex));
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) ev++;
+    lanes++;
+}
+__device__ __forceinline__ void census_flush(const KdCensusLocal &c, KdCensus *out)
+{
+    unsigned long long v[4] = {c.trips, c.lanes, c.tests, c.test_lanes};
+    for (int k = 0; k < 4; k++)
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out->trips, v[0]);
+        atomicAdd(&out->lanes, v[1]);
+        atomicAdd(&out->tests, v[2]);
+        atomicAdd(&out->test_lanes, v[3]);
     }
 }
 
@@ -100,7 +112,7 @@ __device__ __forceinline__ void census_add(unsigned long long *ev, unsigned long
 #define PF_GUARD_K 0.999999523162841796875f /* 1 - 2^-21 */
 
 template <bool PLANAR, bool CENSUS = false>
-__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, KdCensus *census = nullptr)
+__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, KdCensusLocal *census = nullptr)
 {
     // bestDist starts as the distance to the root; visiting the root first reproduces that state
     float sBest = INFINITY;
@@ -108,7 +120,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
     const kd_rsrc_t hot_rsrc = kd_rsrc(t.hot), parent_rsrc = kd_rsrc(t.parent);
     for (;;) {
         while (head >= 0) { // greedy descent
-            if (CENSUS) census_add(&census->trips, &census->lanes);
+            if (CENSUS) census_add(census->trips, census->lanes);
             const uint4 nd = kd_load_hot(hot_rsrc, head);
             // (node - query) as a 2-vector: v_pk_add_f32 / v_pk_mul_f32, one rounding per component as in the scalar form
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -153,7 +165,7 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         }
         // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
         if (bestIdx == prevBest) break;
-        if (CENSUS) census_add(&census->tests, &census->test_lanes);
+        if (CENSUS) census_add(census->tests, census->test_lanes);
         prevBest = bestIdx;
         const float bestDist = fsqrt(sBest);
         const int pi = kd_load_i32(parent_rsrc, bestIdx);

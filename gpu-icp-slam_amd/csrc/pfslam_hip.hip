@@ -70,15 +70,22 @@ struct pfslam_handle {
     pfslam_config cfg;
     int n = 0, nb = 0, dimx = 0, dimy = 0;
     int gn = 0, goff = 0;
+    int stride = 0, world = 1, rank = 0; // shard layout: rank r owns global particles [r * stride, min((r + 1) * stride, gn))
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int variant = 0;
-    // particles, SoA; pos double-buffered for the resample gather
+    // particles, SoA: one block [x | y | theta] of 3 * stride floats (a single all-gather moves all three), double-buffered
+    // for the resample gather; w has `stride` slots too (equal all-gather counts on every rank; the pad stays zero)
+    float *pblk = nullptr, *pblk2 = nullptr;
     float *x = nullptr, *y = nullptr, *th = nullptr, *w = nullptr, *wm = nullptr;
     float *x2 = nullptr, *y2 = nullptr, *th2 = nullptr;
-    // global views for the resample (all ranks' particles); alias the local arrays when not sharded
-    float *gw = nullptr, *gx = nullptr, *gy = nullptr, *gth = nullptr;
+    // global views for the resample (all ranks' particles, rank-major): weights [world * stride], pose blocks
+    // [world][x | y | theta]; they alias the local arrays when not sharded
+    float *gw = nullptr, *gpose = nullptr;
     bool own_global = false;
+    // sharded measurement merge: this rank's {max key, negated-min key, pose of its best particle} (32 bytes) and the
+    // all-gathered records of every rank
+    long long *pack = nullptr, *packs = nullptr;
     float *scan = nullptr;
     // map
     int kd_size = 0, kd_cap = 0, planar = 1;
@@ -207,16 +214,18 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     const int i = order ? order[slot] : slot;
     const float x = px[i], y = py[i], th = pth[i];
     float acc = 0.0f;
+    pf::KdCensusLocal cl = {0, 0, 0, 0};
     for (int j = j0; j < j1; j++) {
         float wx, wy;
         pf::clean_lidar_scan(j, scan[j], th, wx, wy);
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;
             wy += y;
-            const int b = pf::kd_nearest_ref<PLANAR, CENSUS>(tree, wx, wy, 0.0f, census);
+            const int b = pf::kd_nearest_ref<PLANAR, CENSUS>(tree, wx, wy, 0.0f, &cl);
             acc += tree.w[b];
         }
     }
+    if (CENSUS) pf::census_flush(cl, census);
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
 }
 
@@ -483,6 +492,9 @@ static int create_impl(pfslam_handle *h)
     h->nb = cfg->n_beams;
     h->gn = cfg->global_n > 0 ? cfg->global_n : cfg->n_particles;
     h->goff = cfg->global_offset;
+    h->stride = cfg->shard_stride > 0 ? cfg->shard_stride : cfg->n_particles;
+    h->world = (h->gn + h->stride - 1) / h->stride;
+    h->rank = h->goff / h->stride;
     h->dimx = (int)(cfg->map_scale_x / cfg->map_res_x); // map_dim, kernel.cu:120
     h->dimy = (int)(cfg->map_scale_y / cfg->map_res_y);
     h->kd_cap = cfg->kd_capacity;
@@ -493,13 +505,24 @@ static int create_impl(pfslam_handle *h)
     HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    const size_t n = h->n, M = (size_t)h->dimx * h->dimy;
-    CHK(dalloc(&h->x, n)); CHK(dalloc(&h->y, n)); CHK(dalloc(&h->th, n)); CHK(dalloc(&h->w, n)); CHK(dalloc(&h->wm, n));
-    CHK(dalloc(&h->x2, n)); CHK(dalloc(&h->y2, n)); CHK(dalloc(&h->th2, n));
+    const size_t n = h->n, M = (size_t)h->dimx * h->dimy, S = (size_t)h->stride;
+    CHK(dalloc(&h->pblk, 3 * S)); CHK(dalloc(&h->pblk2, 3 * S)); CHK(dalloc(&h->w, S)); CHK(dalloc(&h->wm, S));
+    HIPCHK(hipMemsetAsync(h->pblk, 0, 3 * S * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->pblk2, 0, 3 * S * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->w, 0, S * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->wm, 0, S * 4, h->stream));
+    h->x = h->pblk; h->y = h->pblk + S; h->th = h->pblk + 2 * S;
+    h->x2 = h->pblk2; h->y2 = h->pblk2 + S; h->th2 = h->pblk2 + 2 * S;
+    CHK(dalloc(&h->pack, 4)); CHK(dalloc(&h->packs, (size_t)4 * h->world));
     if (h->gn != h->n) {
-        if (h->goff < 0 || h->goff + h->n > h->gn) return fail("pfslam_create: shard [global_offset, +n_particles) exceeds global_n");
-        CHK(dalloc(&h->gw, (size_t)h->gn)); CHK(dalloc(&h->gx, (size_t)h->gn)); CHK(dalloc(&h->gy, (size_t)h->gn)); CHK(dalloc(&h->gth, (size_t)h->gn));
+        // rank r owns [r * stride, min((r + 1) * stride, gn)): every rank but the last is full, the last one is not empty
+        if (h->goff < 0 || h->goff % h->stride != 0 || h->n > h->stride || h->goff + h->n != std::min(h->goff + h->stride, h->gn))
+            return fail("pfslam_create: shard [global_offset, +n_particles) does not fit the layout rank r = [r * shard_stride, min((r + 1) * shard_stride, global_n))");
+        CHK(dalloc(&h->gw, (size_t)h->world * S)); CHK(dalloc(&h->gpose, (size_t)h->world * 3 * S));
         h->own_global = true;
+    } else {
+        h->gw = h->w;
+        h->gpose = h->pblk;
     }
     CHK(dalloc(&h->scan, (size_t)h->nb));
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
@@ -609,7 +632,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->x, h->y, h->th, h->w, h->wm, h->x2, h->y2, h->th2, h->scan, h->hot, h->parent, h->kz, h->kw,
+    void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->pack, h->packs, h->scan, h->hot, h->parent, h->kz, h->kw,
                     h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->cells, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
@@ -617,7 +640,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_global) {
-        (void)hipFree(h->gw); (void)hipFree(h->gx); (void)hipFree(h->gy); (void)hipFree(h->gth);
+        (void)hipFree(h->gw); (void)hipFree(h->gpose);
     }
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_upd) (void)hipHostFree(h->h_upd);
@@ -902,7 +925,10 @@ static int score_chunks(const pfslam_handle *h)
     return chunks;
 }
 
-__global__ void k_reduce_partials_minmax(const float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats);
+struct ShardPack;
+__global__ void k_reduce_partials_minmax(const float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
+                                         const float *x, const float *y, const float *th, ShardPack *pack);
+__global__ void k_shard_pack(const long long *stats, const float *x, const float *y, const float *th, int n, int goff, ShardPack *pack);
 template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
 static int join_icp(pfslam_handle *h);
 static int launch_stats_reset(pfslam_handle *h, hipStream_t st);
@@ -910,7 +936,7 @@ static int launch_stats_reset(pfslam_handle *h, hipStream_t st);
 // fuse_minmax: the frame loops want the packed min/max keys of this shard right away; the reduce kernel then produces them
 // too (one launch less on the chain).  Needs more than one beam chunk, which every launch below ~8 M particles has.
 // census: run the counting instantiation of the score kernel instead (same launch shape, same results).
-static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus *census = nullptr)
+static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus *census = nullptr, bool shard_pack = false)
 {
     if (h->kd_size <= 0) return fail("pfslam_score_kd: no map loaded");
     const int chunks = score_chunks(h);
@@ -980,7 +1006,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     }
     if (used > 1 && fuse_minmax) {
         hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n, used, order,
-                           h->fit, h->goff, (long long *)h->stats);
+                           h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th, shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr);
         HIPCHK(hipGetLastError());
     } else {
         if (used > 1) {
@@ -991,6 +1017,11 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (fuse_minmax) { // single chunk: the score kernel wrote fit directly
             const int blocks = std::min(1024, (h->n + 255) / 256);
             hipLaunchKernelGGL(k_minmax<float>, dim3(blocks), dim3(256), 0, h->stream, (const float *)h->fit, h->n, h->goff, (long long *)h->stats);
+            HIPCHK(hipGetLastError());
+        }
+        if (fuse_minmax && shard_pack) { // single beam chunk (> 8 M particles or non-integral map weights): the record in its own launch
+            hipLaunchKernelGGL(k_shard_pack, dim3(1), dim3(64), 0, h->stream, (const long long *)h->stats, h->x, h->y, h->th, h->n, h->goff,
+                               (ShardPack *)h->pack);
             HIPCHK(hipGetLastError());
         }
     }
@@ -1160,15 +1191,16 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
     case 2: *ptr = h->x; *bytes = n * 4; break;
     case 3: *ptr = h->y; *bytes = n * 4; break;
     case 4: *ptr = h->th; *bytes = n * 4; break;
-    case 5: *ptr = h->w; *bytes = n * 4; break;
+    case 5: *ptr = h->w; *bytes = (size_t)h->stride * 4; break; // padded to the shard stride (equal all-gather counts)
     case 6: *ptr = h->tile_r; *bytes = ((n + PF_SUM_TILE - 1) / PF_SUM_TILE) * 4; break;
     case 7: *ptr = h->scan; *bytes = (size_t)h->nb * 4; break;
     case 8: *ptr = h->start; *bytes = 16; break;
     case 9: *ptr = h->pose; *bytes = 16; break;
-    case 10: *ptr = h->own_global ? h->gw : h->w; *bytes = (size_t)h->gn * 4; break;
-    case 11: *ptr = h->own_global ? h->gx : h->x; *bytes = (size_t)h->gn * 4; break;
-    case 12: *ptr = h->own_global ? h->gy : h->y; *bytes = (size_t)h->gn * 4; break;
-    case 13: *ptr = h->own_global ? h->gth : h->th; *bytes = (size_t)h->gn * 4; break;
+    case 10: *ptr = h->gw; *bytes = (size_t)h->world * h->stride * 4; break;
+    case 14: *ptr = h->pack; *bytes = 32; break;
+    case 15: *ptr = h->packs; *bytes = (size_t)32 * h->world; break;
+    case 16: *ptr = h->pblk; *bytes = (size_t)3 * h->stride * 4; break;
+    case 17: *ptr = h->gpose; *bytes = (size_t)h->world * 3 * h->stride * 4; break;
     default: return fail("pfslam_device_ptr: unknown buffer");
     }
     return 0;

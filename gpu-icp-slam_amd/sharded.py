@@ -1,18 +1,32 @@
 """Multi-GPU stepping: particles shard over the ranks of one node (one process per GPU), the map, the scan,
-the ICP solve and the map update are replicated, and the merges are a handful of small collectives
-(torch.distributed: backend "nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+the ICP solve and the map update are replicated, and the merges are two small collectives per frame
+(torch.distributed: backend "nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).  The C++ driver
+host/pfslam_mgpu.cpp runs the same protocol on librccl directly.
 
-Per frame:
-    all-reduce MAX  of 2 x int64   packed (fit, -index) keys -> global min / max / first-occurrence argmax
-    all-reduce SUM  of 4 x f32     best particle's pose (zero on the ranks that do not own it)
-    all-gather      of n x f32     weights -> global array (Neff, cdf and sampling run on it, replicated)
-    all-gather      of 3 n x f32   poses, only in frames that resample
-Everything that touches randomness is keyed by GLOBAL particle indices, and every sum runs on the global
-array in the canonical order, so the result is bit-identical for any number of ranks.
+Per frame (include/pfslam.h "multi-GPU"):
+    all-gather  of 32 B per rank        {max key, negated-min key, pose of the shard's best particle}: every rank derives the
+                                        global min / max / first-occurrence argmax and the best pose from the gathered records
+    all-gather  of stride x f32         weights -> global array (Neff, cdf and sampling run on it, replicated); overlapped
+                                        with the replicated map update
+    all-gather  of 3 stride x f32       [x | y | theta] in one piece, only in frames that resample
+Rank r owns the global particles [r * stride, min((r + 1) * stride, N)), stride = ceil(N / world): the last shard may be
+shorter, the exchange buffers are padded to `stride`.  Everything that touches randomness is keyed by GLOBAL particle
+indices, and every sum runs on the global array in the canonical order, so the result is bit-identical for any number of
+ranks.
 
-`engine` is anything with the PfSlam stage interface (the GPU handle in production; the CPU tests plug the
+`engine` is anything with the PfSlam shard interface (the GPU handle in production; the CPU tests plug the
 oracle in to exercise this orchestration under gloo without a GPU)."""
 import numpy as np
+
+
+def shard_layout(n_global, world, rank):
+    """(stride, offset, count) of rank's shard."""
+    stride = (n_global + world - 1) // world
+    off = rank * stride
+    cnt = min(stride, n_global - off)
+    if cnt <= 0:
+        raise ValueError("%d particles over %d ranks leaves rank %d empty (stride %d)" % (n_global, world, rank, stride))
+    return stride, off, cnt
 
 
 class _DevView:
@@ -32,7 +46,7 @@ class GpuBuffers:
         cache = {}
 
         def view(which, typestr, itemsize, dtype):
-            # wrapping a pointer costs ~20 us; the pose buffers only alternate between two addresses, so keep the wrappers
+            # wrapping a pointer costs ~20 us; the pose block only alternates between two addresses, so keep the wrappers
             ptr, nbytes = eng.device_ptr(which)
             key = (ptr, nbytes, typestr)
             t = cache.get(key)
@@ -41,27 +55,26 @@ class GpuBuffers:
             return t
 
         self.stats = view(0, "<i8", 8, torch.int64)
-        self.start = view(8, "<f4", 4, torch.float32)
-        self.w = view(5, "<f4", 4, torch.float32)
-        self.gw = view(10, "<f4", 4, torch.float32)
+        self.pack = view(14, "<i8", 8, torch.int64)     # this rank's 32-byte record
+        self.packs = view(15, "<i8", 8, torch.int64)    # world x 32 bytes
+        self.w = view(5, "<f4", 4, torch.float32)       # stride floats (padded)
+        self.gw = view(10, "<f4", 4, torch.float32)     # world x stride
         self.eng, self._view = eng, view
 
-    def pose_views(self):
-        # x/y/theta swap buffers on every resample, so re-query the pointers
+    def pose_blocks(self):
+        # the local block [x | y | theta] swaps buffers on every resample, so re-query the pointer
         t = self.torch
-        return ([self._view(k, "<f4", 4, t.float32) for k in (2, 3, 4)],
-                [self._view(k, "<f4", 4, t.float32) for k in (11, 12, 13)])
+        return self._view(16, "<f4", 4, t.float32), self._view(17, "<f4", 4, t.float32)
 
 
 class ShardedSlam:
     def __init__(self, pkg, n_global, rank, world, device=0, dist=None, torch=None, engine=None, buffers=None, **kw):
-        if n_global % world:
-            raise ValueError("n_global must be a multiple of the world size (equal shards for all-gather)")
         self.n_global, self.rank, self.world = n_global, rank, world
-        self.n = n_global // world
+        self.stride, self.goff, self.n = shard_layout(n_global, world, rank)
+        shard_layout(n_global, world, world - 1)  # the last rank must not be empty
         self.dist, self.torch = dist, torch
         if engine is None:
-            engine = pkg.PfSlam(self.n, device=device, global_offset=rank * self.n, global_n=n_global, **kw)
+            engine = pkg.PfSlam(self.n, device=device, global_offset=self.goff, global_n=n_global, shard_stride=self.stride, **kw)
             if torch is not None:
                 # run the kernels on torch's current stream so RCCL collectives and kernels are stream-ordered; a stream of
                 # our own rather than the legacy null stream, which synchronises implicitly with every blocking stream
@@ -73,6 +86,7 @@ class ShardedSlam:
         self.eng, self.buf = engine, buffers
         self._last = {}
         self.want_best = True  # trace()['best'] costs one tiny read-back per step; bench.py turns it off
+        self.collectives = 0   # all-gathers issued (2 per frame, 3 in frames that resample)
 
     # -- pass-throughs
     def set_map(self, tree): self.eng.set_map(tree)
@@ -87,34 +101,31 @@ class ShardedSlam:
 
     def _all_gather(self, dst, src, async_op=False):
         """Returns a work handle when async_op (wait() it before the result is used), else None."""
+        self.collectives += 1
         if self.world == 1:
-            dst.copy_(src)
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
             return None
         return self.dist.all_gather_into_tensor(dst, src, async_op=async_op) if async_op else \
             self.dist.all_gather_into_tensor(dst, src)
 
     def step(self, frame, scan):
         """One frame; the host synchronises once (in shard_finish), everything else is enqueued."""
-        e, d, b = self.eng, self.dist, self.buf
+        e, b = self.eng, self.buf
         if e.shard_begin(frame, scan):          # first scan seeds the map (kernel.cu:1714-1717); replicated
             self._last = {"best": -1, "resampled": 0, "kd_size": e.kd_size}
             return
-        if self.world > 1:
-            d.all_reduce(b.stats[:2], op=d.ReduceOp.MAX)
-        e.measurement_apply(fetch=False)        # weights + this rank's share of the best pose
-        if self.world > 1:
-            d.all_reduce(b.start, op=d.ReduceOp.SUM)
-        # the weights are final after measurement_apply: gather them while the (replicated) map update runs
+        self._all_gather(b.packs, b.pack)       # 32 bytes per rank: keys + pose of every shard's best particle
+        e.shard_weights()                       # global min / max / argmax, weights, pose = best + ICP increment
+        # the weights are final: gather them while the (replicated) map update runs
         pending = self._all_gather(b.gw, b.w, async_op=True)
-        e.icp(None, fetch=False)                # adds the increment of the solve that ran under the score kernel
         e.shard_map()                           # replicated map update (device part): the all-gather runs under it
         if pending is not None:
             pending.wait()                      # stream-level: orders the compute stream behind the collective
         did, neff = e.shard_finish(frame)       # Neff on the global weights, header, the one host sync, resample plan
         if did:
-            local, glob = b.pose_views()
-            for dst, src in zip(glob, local):
-                self._all_gather(dst, src)
+            local, glob = b.pose_blocks()
+            self._all_gather(glob, local)       # [x | y | theta] of every rank in one piece
             e.resample_gather()
         best = int(0xFFFFFFFF - (int(b.stats[0].item()) & 0xFFFFFFFF)) if self.want_best else -1
         self._last = {"best": best, "resampled": did, "neff": neff, "kd_size": e.kd_size}

@@ -28,8 +28,8 @@
  *   pfslam_traverse                    findCorrespondenceIndexKD          kernel.cu:924-972
  *   pfslam_topology_update, find_walls,
  *   check_loop_closure, get_topology   UpdateTopology / FindWalls / CheckLoopClosure   kernel.cu:623-795
- *   pfslam_shard_begin / shard_finish  particleFilter split where a multi-GPU caller merges shards (no reference counterpart:
- *                                      the reference is single-GPU)
+ *   pfslam_shard_begin / weights / map / finish   particleFilter split where a multi-GPU caller merges shards (no reference
+ *                                      counterpart: the reference is single-GPU)
  */
 #ifndef PFSLAM_H
 #define PFSLAM_H
@@ -69,10 +69,14 @@ typedef struct pfslam_config {
     int32_t free_upload_bug;    /* 1 = reproduce kernel.cu:1475 (free list tail zero) (H6); 0 = full list */
     int32_t balance_period;     /* 100 = KDTree::Balance at frame%100==5 (kernel.cu:1707); 0 = never */
     /* multi-GPU particle sharding: this handle holds global particles [global_offset, global_offset+n_particles)
-     * of global_n; RNG streams are keyed by the GLOBAL index so results do not depend on the sharding. */
+     * of global_n; RNG streams are keyed by the GLOBAL index so results do not depend on the sharding.
+     * Layout: rank r owns [r * shard_stride, min((r + 1) * shard_stride, global_n)) -- every rank but the last is full,
+     * the last may be shorter (not empty); the exchange buffers are padded to shard_stride so that all-gather counts are
+     * equal on every rank. */
     int32_t global_offset;
     int32_t global_n;      /* 0 -> n_particles */
-    int32_t reserved_[3];
+    int32_t shard_stride;  /* 0 -> n_particles (equal shards) */
+    int32_t reserved_[2];
 } pfslam_config;
 
 typedef struct pfslam_handle pfslam_handle;
@@ -127,7 +131,7 @@ int pfslam_update_map_kd(pfslam_handle *h);
 int pfslam_resample(pfslam_handle *h, int frame, int *resampled, float *neff);
 /* the two halves of pfslam_resample, for sharded handles: plan = Neff + cdf + source indices on the GLOBAL weights
  * (device buffer 10, filled by the caller's all-gather); gather = pull the chosen particles out of the GLOBAL pose
- * arrays (device buffers 11-13, all-gathered by the caller when plan reports resampled = 1) */
+ * blocks (device buffer 17, all-gathered by the caller from buffer 16 when plan reports resampled = 1) */
 int pfslam_resample_plan(pfslam_handle *h, int frame, int *resampled, float *neff);
 int pfslam_resample_gather(pfslam_handle *h);
 int pfslam_score_grid(pfslam_handle *h, int32_t *fit_host);
@@ -157,23 +161,37 @@ int pfslam_get_topology(pfslam_handle *h, float *nodes_xyd, int cap, int *n, int
 int pfslam_maybe_balance(pfslam_handle *h, int frame);
 int pfslam_kd_size(pfslam_handle *h);
 
-/* ---- multi-GPU merge hooks (particles sharded over ranks; collectives are the caller's, e.g. RCCL) ----
- * stats layout (device, 8 x int64): [0] max key, [1] negated-min key (both to be all-reduced with MAX),
- * rest reserved.  key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index).            */
-int pfslam_measurement_local(pfslam_handle *h);  /* score must have run; fills the stats buffer */
-int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, float *fmax); /* after the all-reduce */
-/* The sharded frame in two calls (one host sync per frame, like pfslam_step); the caller's collectives run between
- * them on the handle's stream:  shard_begin -> all-reduce MAX of buffer 0 -> pfslam_measurement_apply -> all-reduce SUM
- * of buffer 8 + all-gather of buffer 5 into buffer 10 -> pfslam_icp -> pfslam_shard_map -> (wait for the all-gather) -> shard_finish -> if *resampled: all-gather of
- * buffers 2-4 into 11-13 -> pfslam_resample_gather.  *seeded = 1 when the frame only seeded the map (first scan). */
+/* ---- multi-GPU (particles sharded over ranks; the collectives are the caller's, e.g. RCCL over xGMI) ----
+ * The sharded frame; the caller's collectives run between the calls on the handle's stream, ONE host sync per frame:
+ *   pfslam_shard_begin      scan upload, re-balance if due, dispersion, score -> this rank's 32-byte record in buffer 14:
+ *                           {int64 max key, int64 negated-min key, float x, y, theta, 0} of the shard's best particle;
+ *                           key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index).  *seeded = 1 when the frame only
+ *                           seeded the map (first scan): nothing else to do for this frame.
+ *   [all-gather buffer 14 -> buffer 15]                        32 bytes per rank
+ *   pfslam_shard_weights    global min / max / first argmax from the gathered records, weight update of this shard, pose =
+ *                           best particle + increment of the ICP solve (which ran under the score kernel)
+ *   [all-gather buffer 5 -> buffer 10]                         weights, shard_stride floats per rank; may overlap with ...
+ *   pfslam_shard_map        ... the replicated map update's device chain (optional call; shard_finish runs it otherwise)
+ *   pfslam_shard_finish     Neff on the gathered weights, host sync, host insert; resample plan when Neff < 0.7 N
+ *   [all-gather buffer 16 -> buffer 17]  pfslam_resample_gather   only when *resampled: [x | y | theta] in ONE piece of
+ *                                                                3 * shard_stride floats per rank
+ * i.e. two collectives per frame, three in frames that resample.  Results are bit-identical for any number of ranks. */
 int pfslam_shard_begin(pfslam_handle *h, int frame, const float *scan_host, int *seeded);
-int pfslam_shard_map(pfslam_handle *h); /* optional, between pfslam_icp and the wait for the weight all-gather: the replicated
-                                         * map update's device chain, so that the all-gather runs under it */
+int pfslam_shard_weights(pfslam_handle *h);
+int pfslam_shard_map(pfslam_handle *h);
 int pfslam_shard_finish(pfslam_handle *h, int frame, int *resampled, float *neff);
+/* stage-level merge hooks (the sharded frame above does not need them): local packed keys into the stats buffer 0
+ * ([0] max key, [1] negated-min key: MAX-reduce across ranks), then weights + this rank's share of the best pose in buffer 8
+ * (zero on non-owners: SUM-reduce across ranks) */
+int pfslam_measurement_local(pfslam_handle *h);  /* score must have run; fills the stats buffer */
+int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, float *fmax); /* after the MAX merge */
 /* device pointers of the handle's buffers, for zero-copy wrapping by the harness.
- * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta, 5 w (n x f32 each), 6 weight tile sums,
- *        7 scan (n_beams x f32), 8 best-particle pose (4 x f32), 9 robot pose (4 x f32),
- *        10 global w, 11 global x, 12 global y, 13 global theta (global_n x f32 each; alias 5,2,3,4 when unsharded) */
+ * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta (n x f32 each; inside buffer 16), 5 w (shard_stride x f32, the
+ *        first n valid), 6 weight tile sums, 7 scan (n_beams x f32), 8 best-particle pose (4 x f32), 9 robot pose (4 x f32),
+ *        10 global w (world * shard_stride x f32, rank-major, the first global_n valid; aliases 5 when unsharded),
+ *        14 this rank's 32-byte measurement record, 15 the gathered records (world x 32 B),
+ *        16 local pose block [x | y | theta] (3 * shard_stride x f32; moves when a resample swaps the double buffer),
+ *        17 global pose blocks (world x 3 * shard_stride x f32, rank-major; aliases 16 when unsharded) */
 int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
 
 /* ---- measurement support ----

@@ -55,23 +55,35 @@ class OracleBuffers:
     def __init__(self, eng):
         self.eng = eng
         self.stats = torch.from_numpy(eng.stats)
-        self.start = torch.from_numpy(eng.start)
-        self.w = torch.from_numpy(eng.w)
-        self.gw = torch.from_numpy(eng.gw)
+        self.pack = torch.from_numpy(eng.pack)
+        self.packs = torch.from_numpy(eng.packs)
+        self.w = torch.from_numpy(eng.w_pad)
+        self.gw = torch.from_numpy(eng.gw_pad)
 
-    def pose_views(self):
-        e = self.eng
-        return ([torch.from_numpy(a) for a in (e.x, e.y, e.th)], [torch.from_numpy(a) for a in (e.gx, e.gy, e.gth)])
+    def pose_blocks(self):
+        return torch.from_numpy(self.eng.pblk), torch.from_numpy(self.eng.gpose)
 
 
 class OracleShardEngine:
-    def __init__(self, n_local, goff, gn, kd_capacity=1 << 16, strict_host_mirror=1, balance_period=100):
+    """Rank `goff // stride` of a job of `gn` particles: the same buffers as the GPU handle (include/pfslam.h, buffers 5, 10,
+    14-17), padded to the shard stride."""
+
+    def __init__(self, n_local, goff, gn, kd_capacity=1 << 16, strict_host_mirror=1, balance_period=100, stride=0):
         self.n, self.goff, self.gn, self.cap = n_local, goff, gn, kd_capacity
+        self.stride = stride or n_local
+        self.world = (gn + self.stride - 1) // self.stride
         self.strict, self.period = strict_host_mirror, balance_period
         z = lambda k: np.zeros(k, np.float32)
-        self.x, self.y, self.th, self.w, self.wm = z(n_local), z(n_local), z(n_local), np.ones(n_local, np.float32), np.ones(n_local, np.float32)
-        self.gw, self.gx, self.gy, self.gth = z(gn), z(gn), z(gn), z(gn)
+        S, n = self.stride, n_local
+        self.pblk = z(3 * S)                         # [x | y | theta], stride slots each
+        self.x, self.y, self.th = self.pblk[0:n], self.pblk[S:S + n], self.pblk[2 * S:2 * S + n]
+        self.w_pad = z(S); self.w = self.w_pad[:n]; self.w[:] = 1
+        self.wm = np.ones(n, np.float32)
+        self.gw_pad = z(self.world * S); self.gw = self.gw_pad[:gn]
+        self.gpose = z(self.world * 3 * S)
         self.stats = np.zeros(8, np.int64)
+        self.pack = np.zeros(4, np.int64)            # {kmax, kmin, (x, y) bits, (theta, 0) bits}
+        self.packs = np.zeros(4 * self.world, np.int64)
         self.start = z(4)
         self.tree = np.zeros(kd_capacity, O.NODE_DTYPE)
         self.size = 0
@@ -79,6 +91,7 @@ class OracleShardEngine:
         self.fit = z(n_local)
         self.scan = None
         self.src = None
+        self.icp_delta = None
 
     # ---- helpers
     def _aos(self):
@@ -123,7 +136,7 @@ class OracleShardEngine:
         self.stats[0] = np.max((f32_to_ordered(self.fit) << 32) | (0xFFFFFFFF - gi))
         self.stats[1] = np.max(f32_to_ordered(-self.fit) << 32)
 
-    def measurement_apply(self, fetch=True):
+    def _apply_weights(self):
         fmax = ordered_to_f32(self.stats[0] >> 32)
         fmin = -ordered_to_f32(self.stats[1] >> 32)
         best = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF))
@@ -135,24 +148,36 @@ class OracleShardEngine:
         mirror = (self.gn + 1) // 2 if self.strict else 1 << 62
         sel = (self.goff + np.arange(self.n)) < mirror
         self.wm[sel] = self.w[sel]
-        lb = best - self.goff
-        self.start[:] = 0
-        if 0 <= lb < self.n:
-            self.start[:3] = (self.x[lb], self.y[lb], self.th[lb])
         return best, float(fmin), float(fmax)
 
     def shard_begin(self, frame, scan):
-        """pfslam_shard_begin: scan, re-balance if due, (first scan: seed the map), dispersion, score, local keys."""
+        """pfslam_shard_begin: scan, re-balance if due, (first scan: seed the map), dispersion, score, this rank's record."""
         self.set_scan(scan)
         self.maybe_balance(frame)
         if self.size == 0:
             self.set_pose(np.zeros(3, np.float32))
             self.update_map_kd()
             return True
+        # the replicated ICP solve depends on the scan, the previous pose and the map only (kernel.cu:984-990, 1081-1092)
+        zero = np.zeros(3, np.float32)
+        inc, _ = O.icp(self.tree, self.robot, zero, self.scan)
+        self.icp_delta = inc.copy()
         self.motion_update(frame)
         self.score_kd(fetch=False)
         self.measurement_local()
+        lb = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF)) - self.goff
+        self.pack[0], self.pack[1] = self.stats[0], self.stats[1]
+        self.pack[2:].view(np.float32)[:] = (self.x[lb], self.y[lb], self.th[lb], 0.0)
         return False
+
+    def shard_weights(self):
+        """pfslam_shard_weights: merge the gathered records, weights, pose = best particle + ICP increment."""
+        rec = self.packs.reshape(self.world, 4)
+        owner = int(np.argmax(rec[:, 0]))            # first occurrence of the maximum key
+        self.stats[0], self.stats[1] = rec[owner, 0], rec[:, 1].max()
+        self.start[:] = rec[owner, 2:].copy().view(np.float32)
+        self._apply_weights()
+        self.robot[:] = self.start[:3] + self.icp_delta
 
     def shard_map(self):
         """pfslam_shard_map: the replicated map update at the ICP pose."""
@@ -162,27 +187,25 @@ class OracleShardEngine:
         """pfslam_shard_finish: Neff / resample plan on the gathered weights."""
         return self.resample_plan(frame)
 
-    def icp(self, start=None, fetch=True):
-        s = self.start[:3] if start is None else np.asarray(start, np.float32)
-        pose, dbg = O.icp(self.tree, self.robot, s, self.scan)
-        self.robot[:] = pose
-        return pose, dbg
-
     def resample_plan(self, frame):
         L = O.lib()
-        w2 = (self.gw * self.gw).astype(np.float32)
-        r = np.float32(L.orc_sum_f32(O.P(self.gw), self.gn, 1))
+        gw = np.ascontiguousarray(self.gw)
+        w2 = (gw * gw).astype(np.float32)
+        r = np.float32(L.orc_sum_f32(O.P(gw), self.gn, 1))
         r2 = np.float32(L.orc_sum_f32(O.P(w2), self.gn, 1))
         neff = np.float32(r * r) / r2
         did = float(neff) < 0.7 * self.gn
         if did:
             cdf = np.zeros(self.gn, np.float32)
-            L.orc_inclusive_scan_f32(O.P(self.gw), self.gn, O.P(cdf))
+            L.orc_inclusive_scan_f32(O.P(gw), self.gn, O.P(cdf))
             self.src = np.zeros(self.n, np.int32)
             L.orc_weighted_sample_indices(O.P(cdf), self.gn, float(neff), frame, self.goff, self.n, O.P(self.src))
         return int(did), float(neff)
 
     def resample_gather(self):
-        self.x[:], self.y[:], self.th[:] = self.gx[self.src], self.gy[self.src], self.gth[self.src]
+        S = self.stride
+        r, k = self.src // S, self.src % S
+        blk = r.astype(np.int64) * 3 * S
+        self.x[:], self.y[:], self.th[:] = self.gpose[blk + k], self.gpose[blk + S + k], self.gpose[blk + 2 * S + k]
         self.w[:] = 1
         self.wm[:] = 1

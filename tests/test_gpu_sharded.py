@@ -1,4 +1,4 @@
-"""Sharded handles on ONE GPU: two 'virtual ranks' (global offsets 0 and n/2) are stepped stage by stage with
+"""Sharded handles on ONE GPU: 'virtual ranks' are stepped through the sharded frame with
 the collectives done by hand on the zero-copy torch views; the result must equal the unsharded oracle and the
 unsharded GPU step bit for bit.  (The real multi-process path is covered under gloo in test_sharded_gloo.py.)"""
 import importlib
@@ -15,60 +15,61 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.int32)
 
 
-def test_two_virtual_ranks_on_one_gpu_match_oracle(pkg):
+@pytest.mark.parametrize("n_global,world", [(1000, 2), (1001, 3)])
+def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
+    """The sharded frame of include/pfslam.h with the all-gathers done by hand between handles that share one GPU: equal
+    shards (2 x 500) and a ragged job (1001 = 334 + 334 + 333, exchange buffers padded to the stride)."""
     torch = pytest.importorskip("torch")
     assert pkg.device_count() > 0 and torch.cuda.is_available()
     sharded = importlib.import_module("gpu-icp-slam_amd.sharded")
-    n_global, world, n_frames = 1000, 2, 12
-    n = n_global // world
-    engs = [pkg.PfSlam(n, kd_capacity=1 << 16, global_offset=r * n, global_n=n_global) for r in range(world)]
+    n_frames = 12
+    lay = [sharded.shard_layout(n_global, world, r) for r in range(world)]
+    engs = [pkg.PfSlam(cnt, kd_capacity=1 << 16, global_offset=off, global_n=n_global, shard_stride=stride) for stride, off, cnt in lay]
     bufs = [sharded.GpuBuffers(e, torch, 0) for e in engs]
     o = O.Slam(n_global, kd_capacity=1 << 16)
     segs, frames = pkg.synth.corridor_sequence(n_frames, seed=5)
     n_resampled = 0
+
+    def sync():
+        for e in engs:
+            e.synchronize()
+        torch.cuda.synchronize()
+
     for f, (pose, scan) in enumerate(frames, start=1):
         o.step(f, scan)
-        for e in engs:
-            e.set_scan(scan); e.maybe_balance(f)
-        if engs[0].kd_size == 0:
-            for e in engs:
-                e.set_pose(np.zeros(3, np.float32)); e.update_map_kd()
+        seeded = [e.shard_begin(f, scan) for e in engs]
+        assert len(set(seeded)) == 1
+        if seeded[0]:
             continue
-        for e in engs:
-            e.motion_update(f); e.score_kd(fetch=False); e.measurement_local(); e.synchronize()
-        merged = torch.maximum(bufs[0].stats[:2], bufs[1].stats[:2])          # all-reduce MAX
+        sync()
+        packs = torch.cat([b.pack for b in bufs])                               # all-gather of the 32-byte records
         for b in bufs:
-            b.stats[:2].copy_(merged)
-        torch.cuda.synchronize()
-        res = [e.measurement_apply() for e in engs]
-        assert res[0] == res[1]
-        start = bufs[0].start + bufs[1].start                                   # all-reduce SUM
-        for b in bufs:
-            b.start.copy_(start)
-        torch.cuda.synchronize()
+            b.packs.copy_(packs)
+        sync()
         for e in engs:
-            e.icp(None); e.synchronize()
-        gw = torch.cat([bufs[0].w, bufs[1].w])                                   # all-gather
+            e.shard_weights()
+        sync()
+        gw = torch.cat([b.w for b in bufs])                                     # all-gather of the (padded) weights
         for b in bufs:
             b.gw.copy_(gw)
-        torch.cuda.synchronize()
+        sync()
         for e in engs:
-            e.update_map_kd()
-        plans = [e.resample_plan(f) for e in engs]
-        assert plans[0] == plans[1]
+            e.shard_map()
+        plans = [e.shard_finish(f) for e in engs]
+        assert len(set(plans)) == 1
         if plans[0][0]:
             n_resampled += 1
-            views = [b.pose_views() for b in bufs]
-            for k in range(3):
-                g = torch.cat([views[0][0][k], views[1][0][k]])
-                for v in views:
-                    v[1][k].copy_(g)
-            torch.cuda.synchronize()
+            blocks = [b.pose_blocks() for b in bufs]
+            g = torch.cat([loc for loc, _ in blocks])                           # all-gather of the [x | y | theta] blocks
+            for _, glob in blocks:
+                glob.copy_(g)
+            sync()
             for e in engs:
                 e.resample_gather()
         t = o.trace()
-        assert res[0][0] == t["best"] and plans[0][0] == t["resampled"]
+        assert plans[0][0] == t["resampled"]
         for e in engs:
+            assert e.trace()["best"] == t["best"]
             assert (bits(e.pose) == bits(o.pose)).all()
             assert e.kd_size == o.kd_size
     assert n_resampled > 0

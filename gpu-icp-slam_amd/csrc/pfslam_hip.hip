@@ -132,6 +132,8 @@ struct pfslam_handle {
     std::vector<std::vector<unsigned>> topo_edges{std::vector<unsigned>()};
     unsigned topo_idx = 0;
     int *d_count = nullptr;
+    int topo_in_step = 0;               // pfslam_set_topology: UpdateTopology + CheckLoopClosure at the end of every frame
+    std::vector<int32_t> frame_closures; // (candidate node, visible node) pairs proposed by the last frame
     // host mirrors / read-back
     // device->host: [HostHeader | new walls (float4 x max_wall)], one copy per step into pinned memory
     uint8_t *d_out = nullptr, *h_out = nullptr, *out_dev = nullptr; // out_dev: where the kernels write (d_out, or h_out's device view)

@@ -1,0 +1,344 @@
+// pfslam_mgpu.cpp -- multi-GPU driver in C++ on librccl directly: one process per GPU, particles sharded over the ranks,
+// map / scan / ICP / map update replicated, two all-gathers per frame (three in frames that resample) over xGMI.
+// The protocol is the sharded frame of include/pfslam.h (pfslam_shard_begin / weights / map / finish); the Python harness
+// gpu-icp-slam_amd/sharded.py runs the same protocol through torch.distributed.
+//
+//   pfslam_mgpu --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX]
+//               [--global-particles G]
+//
+// Launcher mode (no rank in the environment): starts N copies of itself, one per GPU (fork + exec, so no process inherits
+// an initialised HIP / RCCL runtime), and waits for them.  Rank mode: PFSLAM_RANK / PFSLAM_WORLD / PFSLAM_LOCAL_RANK, or the
+// torchrun names RANK / WORLD_SIZE / LOCAL_RANK; the ncclUniqueId travels through the file PFSLAM_ID_FILE (rank 0 writes
+// it, the others wait for it).
+// MAP.nodes : KDTree::Node array (kdtree.hpp:16-27, 32 bytes per node);  SCANS.f32 : frames x 1081 float32.
+// Rank 0 prints ONE JSON line of the same form as bench.py's: whole-job particle-scan evaluations per second over exactly K
+// steps, barrier + stream synchronisation on both sides, MAX over the ranks.  --dump writes every rank's final particles and
+// map (PREFIX.rank<r>.particles / .nodes) for bit-comparison with a single-handle pfslam_step run.
+// --global-particles G: total particle count when it is not N x PARTICLES_PER_GPU (ragged last shard).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "../../include/pfslam.h"
+
+static int g_rank = 0;
+#define PF(call)                                                                                          \
+    do {                                                                                                  \
+        if (call) {                                                                                       \
+            fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, pfslam_last_error());                    \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
+#define HIP(call)                                                                                         \
+    do {                                                                                                  \
+        hipError_t e__ = (call);                                                                          \
+        if (e__ != hipSuccess) {                                                                          \
+            fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, hipGetErrorString(e__));                 \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
+#define NCCL(call)                                                                                        \
+    do {                                                                                                  \
+        ncclResult_t r__ = (call);                                                                        \
+        if (r__ != ncclSuccess) {                                                                         \
+            fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, ncclGetErrorString(r__));                \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
+
+static std::vector<char> slurp(const char *path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) {
+        fprintf(stderr, "cannot open %s\n", path);
+        exit(EXIT_FAILURE);
+    }
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static const char *env_any(const char *a, const char *b)
+{
+    const char *v = getenv(a);
+    return v ? v : getenv(b);
+}
+
+struct Args {
+    int gpus = 1, steps = 20, warmup = 5, first_frame = 6;
+    long global_particles = 0;
+    std::string map, scans, dump;
+    int particles = 0;
+};
+
+static bool parse(int argc, char **argv, Args &a)
+{
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+        const std::string s = argv[i];
+        auto next = [&](int &dst) { if (i + 1 < argc) dst = atoi(argv[++i]); };
+        if (s == "--gpus") next(a.gpus);
+        else if (s == "--steps") next(a.steps);
+        else if (s == "--warmup") next(a.warmup);
+        else if (s == "--first-frame") next(a.first_frame);
+        else if (s == "--global-particles") { if (i + 1 < argc) a.global_particles = atol(argv[++i]); }
+        else if (s == "--dump") { if (i + 1 < argc) a.dump = argv[++i]; }
+        else pos.push_back(s);
+    }
+    if (pos.size() < 3) return false;
+    a.map = pos[0];
+    a.scans = pos[1];
+    a.particles = atoi(pos[2].c_str());
+    return a.gpus >= 1 && a.particles > 0 && a.steps > 0 && a.warmup >= 0;
+}
+
+// ---- launcher: N copies of this binary, one per GPU ---------------------------------------------------------------
+static int launch(int argc, char **argv, const Args &a)
+{
+    char tmpl[] = "/tmp/pfslam_mgpu_XXXXXX";
+    if (!mkdtemp(tmpl)) {
+        perror("mkdtemp");
+        return 1;
+    }
+    const std::string id_file = std::string(tmpl) + "/nccl_id";
+    std::vector<pid_t> kids;
+    for (int r = 0; r < a.gpus; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) {
+            perror("fork");
+            return 1;
+        }
+        if (pid == 0) {
+            setenv("PFSLAM_RANK", std::to_string(r).c_str(), 1);
+            setenv("PFSLAM_WORLD", std::to_string(a.gpus).c_str(), 1);
+            setenv("PFSLAM_LOCAL_RANK", std::to_string(r).c_str(), 1);
+            setenv("PFSLAM_ID_FILE", id_file.c_str(), 1);
+            execv("/proc/self/exe", argv);
+            perror("execv");
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t pid : kids) {
+        int st = 0;
+        waitpid(pid, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+    }
+    unlink(id_file.c_str());
+    rmdir(tmpl);
+    (void)argc;
+    return rc;
+}
+
+// ---- one rank ---------------------------------------------------------------------------------------------------------
+static int get_id(int rank, const std::string &path, ncclUniqueId &id)
+{
+    if (rank == 0) {
+        NCCL(ncclGetUniqueId(&id));
+        const std::string tmp = path + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) {
+            fprintf(stderr, "cannot write %s\n", tmp.c_str());
+            return 1;
+        }
+        fclose(f);
+        if (rename(tmp.c_str(), path.c_str())) { // atomic: readers never see a partial id
+            perror("rename");
+            return 1;
+        }
+        return 0;
+    }
+    for (int tries = 0; tries < 6000; tries++) { // up to 60 s
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id)) {
+            FILE *f = fopen(path.c_str(), "rb");
+            if (f && fread(&id, sizeof(id), 1, f) == 1) {
+                fclose(f);
+                return 0;
+            }
+            if (f) fclose(f);
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    fprintf(stderr, "[rank %d] no ncclUniqueId in %s after 60 s\n", rank, path.c_str());
+    return 1;
+}
+
+struct Buffers { // device pointers of the handle's exchange buffers (pfslam_device_ptr)
+    void *pack, *packs, *w, *gw, *pose_blk, *gpose;
+};
+static int query(pfslam_handle *h, Buffers &b)
+{
+    size_t bytes;
+    PF(pfslam_device_ptr(h, 14, &b.pack, &bytes));
+    PF(pfslam_device_ptr(h, 15, &b.packs, &bytes));
+    PF(pfslam_device_ptr(h, 5, &b.w, &bytes));
+    PF(pfslam_device_ptr(h, 10, &b.gw, &bytes));
+    PF(pfslam_device_ptr(h, 16, &b.pose_blk, &bytes)); // moves when a resample swaps the double buffer
+    PF(pfslam_device_ptr(h, 17, &b.gpose, &bytes));
+    return 0;
+}
+
+struct Rank {
+    pfslam_handle *h = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_w = nullptr, ev_g = nullptr;
+    int stride = 0, collectives = 0;
+};
+
+// the sharded frame of include/pfslam.h; ONE host sync (inside pfslam_shard_finish)
+static int step(Rank &R, int frame, const float *scan)
+{
+    int seeded = 0;
+    PF(pfslam_shard_begin(R.h, frame, scan, &seeded));
+    if (seeded) return 0; // the first scan only seeds the (replicated) map
+    Buffers b;
+    if (query(R.h, b)) return 1;
+    NCCL(ncclAllGather(b.pack, b.packs, 32, ncclChar, R.comm, R.stream)); // keys + pose of every shard's best particle
+    PF(pfslam_shard_weights(R.h));
+    // the weights are final: gather them on the side stream while the replicated map update runs on the main one
+    HIP(hipEventRecord(R.ev_w, R.stream));
+    HIP(hipStreamWaitEvent(R.comm_stream, R.ev_w, 0));
+    NCCL(ncclAllGather(b.w, b.gw, (size_t)R.stride, ncclFloat, R.comm, R.comm_stream));
+    HIP(hipEventRecord(R.ev_g, R.comm_stream));
+    PF(pfslam_shard_map(R.h));
+    HIP(hipStreamWaitEvent(R.stream, R.ev_g, 0));
+    int resampled = 0;
+    float neff = 0.0f;
+    PF(pfslam_shard_finish(R.h, frame, &resampled, &neff));
+    R.collectives += 2;
+    if (resampled) {
+        if (query(R.h, b)) return 1;
+        NCCL(ncclAllGather(b.pose_blk, b.gpose, (size_t)3 * R.stride, ncclFloat, R.comm, R.stream)); // [x | y | theta] in one piece
+        PF(pfslam_resample_gather(R.h));
+        R.collectives += 1;
+    }
+    return 0;
+}
+
+static int barrier(Rank &R, double *max_inout, double *scratch_dev)
+{
+    // all-reduce MAX of one double: a barrier, and the max-over-ranks of the elapsed time when asked for
+    double v = max_inout ? *max_inout : 0.0;
+    HIP(hipMemcpyAsync(scratch_dev, &v, 8, hipMemcpyHostToDevice, R.stream));
+    NCCL(ncclAllReduce(scratch_dev, scratch_dev, 1, ncclDouble, ncclMax, R.comm, R.stream));
+    HIP(hipMemcpyAsync(&v, scratch_dev, 8, hipMemcpyDeviceToHost, R.stream));
+    HIP(hipStreamSynchronize(R.stream));
+    HIP(hipStreamSynchronize(R.comm_stream));
+    if (max_inout) *max_inout = v;
+    return 0;
+}
+
+static int run_rank(const Args &a, int rank, int world, int local_rank, const std::string &id_file)
+{
+    g_rank = rank;
+    const std::vector<char> map = slurp(a.map.c_str()), scans = slurp(a.scans.c_str());
+    const int n_nodes = (int)(map.size() / sizeof(pfslam_node)), beams = 1081;
+    const int n_frames = (int)(scans.size() / (beams * sizeof(float)));
+    if (n_nodes <= 0 || n_frames <= 0) {
+        fprintf(stderr, "empty map or scan file\n");
+        return 1;
+    }
+    // shard layout: rank r owns [r * stride, min((r + 1) * stride, G))
+    const long G = a.global_particles > 0 ? a.global_particles : (long)a.particles * world;
+    const int stride = (int)((G + world - 1) / world);
+    const long off = (long)rank * stride;
+    const int count = (int)std::min<long>(stride, G - off);
+    if (count <= 0) {
+        fprintf(stderr, "[rank %d] empty shard: %ld particles over %d ranks\n", rank, G, world);
+        return 1;
+    }
+    HIP(hipSetDevice(local_rank));
+    ncclUniqueId id;
+    if (get_id(rank, id_file, id)) return 1;
+    Rank R;
+    NCCL(ncclCommInitRank(&R.comm, world, id, rank));
+    HIP(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+    HIP(hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
+    HIP(hipEventCreateWithFlags(&R.ev_w, hipEventDisableTiming));
+    HIP(hipEventCreateWithFlags(&R.ev_g, hipEventDisableTiming));
+    R.stride = stride;
+    pfslam_config cfg;
+    pfslam_default_config(&cfg);
+    cfg.n_particles = count;
+    cfg.kd_capacity = n_nodes + (1 << 18);
+    cfg.device = local_rank;
+    cfg.global_offset = (int)off;
+    cfg.global_n = (int)G;
+    cfg.shard_stride = stride;
+    PF(pfslam_create(&cfg, &R.h));
+    PF(pfslam_set_stream(R.h, R.stream));
+    PF(pfslam_set_map(R.h, reinterpret_cast<const pfslam_node *>(map.data()), n_nodes));
+    double *scratch = nullptr;
+    HIP(hipMalloc((void **)&scratch, 8));
+    const float *s = reinterpret_cast<const float *>(scans.data());
+    for (int f = 1; f <= 5; f++) PF(pfslam_motion_update(R.h, f)); // same dispersed starting cloud as bench.py
+    int frame = a.first_frame, k = 0;
+    for (int i = 0; i < a.warmup; i++, k++)
+        if (step(R, frame++, s + (size_t)(k % n_frames) * beams)) return 1;
+    if (barrier(R, nullptr, scratch)) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < a.steps; i++, k++)
+        if (step(R, frame++, s + (size_t)(k % n_frames) * beams)) return 1;
+    if (barrier(R, nullptr, scratch)) return 1;
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (barrier(R, &sec, scratch)) return 1; // MAX over the ranks
+    float pose[3];
+    PF(pfslam_get_pose(R.h, pose));
+    if (!a.dump.empty()) {
+        const pfslam_particle *p;
+        const pfslam_node *nd;
+        int np = 0, nn = 0;
+        PF(pfslam_get_particles(R.h, &p, &np));
+        std::ofstream(a.dump + ".rank" + std::to_string(rank) + ".particles", std::ios::binary).write((const char *)p, (size_t)np * sizeof(*p));
+        PF(pfslam_get_map(R.h, &nd, &nn));
+        std::ofstream(a.dump + ".rank" + std::to_string(rank) + ".nodes", std::ios::binary).write((const char *)nd, (size_t)nn * sizeof(*nd));
+    }
+    if (rank == 0) {
+        printf("{\"metric\": \"particle-scan evals/sec (1081 beams x N particles), full particleFilter step, KD path\", \"value\": %.6e, "
+               "\"unit\": \"particle-scan evals/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.6f, "
+               "\"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, \"dtype\": \"f32\", \"data\": \"synthetic\", "
+               "\"config\": {\"workload\": \"1081-beam scans, %d particles/GPU, %d-point KD map, full SLAM step\", \"particles_global\": %ld, "
+               "\"parallelism\": \"particles sharded x%d, map replicated\", \"kd_size_end\": %d, \"driver\": \"C++ / librccl (host/pfslam_mgpu.cpp)\", "
+               "\"collectives\": %d, \"pose\": [%.9g, %.9g, %.9g]}}\n",
+               (double)G * a.steps / sec, world, a.steps, a.warmup, sec / a.steps * 1e3, stride, n_nodes, G, world, pfslam_kd_size(R.h),
+               R.collectives, pose[0], pose[1], pose[2]);
+        fflush(stdout);
+    }
+    PF(pfslam_destroy(R.h));
+    (void)hipFree(scratch);
+    NCCL(ncclCommDestroy(R.comm));
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    Args a;
+    if (!parse(argc, argv, a)) {
+        printf("Usage: %s --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX] "
+               "[--global-particles G]\n", argv[0]);
+        return 1;
+    }
+    const char *rk = env_any("PFSLAM_RANK", "RANK");
+    if (!rk) return launch(argc, argv, a);
+    const char *ws = env_any("PFSLAM_WORLD", "WORLD_SIZE"), *lr = env_any("PFSLAM_LOCAL_RANK", "LOCAL_RANK");
+    const int rank = atoi(rk), world = ws ? atoi(ws) : 1, local_rank = lr ? atoi(lr) : rank;
+    std::string id_file = getenv("PFSLAM_ID_FILE") ? getenv("PFSLAM_ID_FILE") : "";
+    if (id_file.empty()) {
+        const char *port = getenv("MASTER_PORT");
+        id_file = std::string("/tmp/pfslam_nccl_id.") + (port ? port : "0");
+    }
+    return run_rank(a, rank, world, local_rank, id_file);
+}

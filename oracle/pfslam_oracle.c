@@ -1169,6 +1169,11 @@ struct orc_slam {
     int n_wall, n_free;
     int8_t *grid;   /* occupancyGrid, kernel.cu:122-124 (allocated on first grid use) */
     int32_t *fit_i; /* dev_fit */
+    /* UpdateTopology / CheckLoopClosure at the end of the frame (kernel.cu:1750-1751, commented out in the shipped step) */
+    int topo_in_step;
+    orc_topology *topo;
+    int32_t *closures; /* pairs proposed by the last frame */
+    int n_closures;
 };
 
 orc_slam *orc_slam_create(const orc_slam_config *cfg)
@@ -1205,7 +1210,7 @@ void orc_slam_destroy(orc_slam *s)
     if (!s) return;
     free(s->dev); free(s->host); free(s->kd); free(s->fit); free(s->free_mask); free(s->wall_mask);
     free(s->wall_pts); free(s->free_pts); free(s->wall_c); free(s->free_c); free(s->create);
-    free(s->grid); free(s->fit_i);
+    free(s->grid); free(s->fit_i); free(s->topo); free(s->closures);
     free(s);
 }
 
@@ -1260,6 +1265,37 @@ static void orc_pf_update_map_kd(orc_slam *s, const float *scan)
     s->trace[4] = n_insert;
 }
 
+/* The two calls the reference leaves commented out at the end of particleFilter (kernel.cu:1750-1751), where they stand.
+ * FindWalls reads the 2-D occupancy grid (dev_occupancyGrid, kernel.cu:680), which the KD path never updates: there it stays
+ * at its initial -100 and every node is "visible"; in the 2-D frame loop it is the live map. */
+#define ORC_MAX_CLOSURES 65536
+static void orc_slam_grid_alloc(orc_slam *s);
+static void orc_slam_frame_topology(orc_slam *s)
+{
+    if (!s->topo_in_step) return;
+    orc_slam_grid_alloc(s);
+    orc_topology_update(s->topo, s->robot);
+    int n = orc_check_loop_closure(s->topo, s->grid, s->dimx, s->dimy, &s->cfg.patch, s->robot, s->closures, ORC_MAX_CLOSURES);
+    s->n_closures = n < ORC_MAX_CLOSURES ? n : ORC_MAX_CLOSURES;
+}
+void orc_slam_set_topology(orc_slam *s, int enable)
+{
+    s->topo_in_step = enable;
+    if (enable && !s->topo) {
+        s->topo = (orc_topology *)calloc(1, sizeof(orc_topology));
+        orc_topology_init(s->topo);
+        s->closures = (int32_t *)calloc((size_t)2 * ORC_MAX_CLOSURES, sizeof(int32_t));
+    }
+    s->n_closures = 0;
+}
+int orc_slam_last_closures(const orc_slam *s, int32_t *pairs, int cap)
+{
+    int n = s->n_closures < cap ? s->n_closures : cap;
+    if (n > 0) memcpy(pairs, s->closures, (size_t)n * 8);
+    return s->n_closures;
+}
+const orc_topology *orc_slam_topology(const orc_slam *s) { return s->topo; }
+
 void orc_slam_step(orc_slam *s, int frame, const float *scan)
 {
     int n = s->cfg.n_particles;
@@ -1312,6 +1348,7 @@ void orc_slam_step(orc_slam *s, int frame, const float *scan)
         if (did) memcpy(s->host, s->dev, sizeof(orc_particle) * (size_t)n);
         s->trace[1] = did;
         memcpy(&s->trace[5], &neff, 4);
+        orc_slam_frame_topology(s); /* //UpdateTopology(); //CheckLoopClosure(); kernel.cu:1750-1751 */
     }
     s->trace[6] = s->kd_size;
 }
@@ -1374,6 +1411,7 @@ void orc_slam_step_grid(orc_slam *s, int frame, const float *scan)
     if (did) memcpy(s->host, s->dev, sizeof(orc_particle) * (size_t)n);
     s->trace[1] = did;
     memcpy(&s->trace[5], &neff, 4);
+    orc_slam_frame_topology(s);
 }
 
 /* The reference's own CPU path of the 2-D frame loop: the `GPU_* == 0` branches (H7 semantics, which DIFFER from the GPU

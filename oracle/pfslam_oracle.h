@@ -168,6 +168,10 @@ void orc_slam_set_map(orc_slam *s, const orc_node *tree, int n);
 void orc_slam_step(orc_slam *s, int frame, const float *scan);
 /* 2-D grid variant (stages kernel.cu:400-418, 307-339, 551-577, 447-511 in the frame loop of 1702-1762) */
 void orc_slam_step_grid(orc_slam *s, int frame, const float *scan);
+/* run UpdateTopology + CheckLoopClosure at the end of every frame (the two calls commented out at kernel.cu:1750-1751) */
+void orc_slam_set_topology(orc_slam *s, int enable);
+int orc_slam_last_closures(const orc_slam *s, int32_t *pairs, int cap); /* returns the number of pairs of the last frame */
+const orc_topology *orc_slam_topology(const orc_slam *s);
 /* the reference's CPU branches of the same loop (GPU_* == 0; H7 semantics; timing baseline for BASELINE configs[0]) */
 void orc_slam_step_grid_cpu(orc_slam *s, int frame, const float *scan);
 void orc_slam_set_grid(orc_slam *s, const int8_t *grid);

@@ -135,3 +135,46 @@ def test_cpp_bench_driver_matches_python_driver(tmp_path, pkg):
     assert d["kd_size_end"] == h.trace()["kd_size"]
     assert np.allclose(d["pose"], h.pose, atol=5e-7)   # printed with 6 decimals
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("particles", [3000, 3001])
+def test_cpp_rccl_driver_world1_is_bit_identical_to_pfslam_step(tmp_path, pkg, particles):
+    """host/pfslam_mgpu (C++ on librccl: ncclCommInitRank, ncclAllGather over the sharded frame of include/pfslam.h) with
+    ONE rank: the launcher starts the rank process, RCCL runs the frame's all-gathers (in place at world = 1), and the final
+    particles, map and pose are bit-identical to a single handle driven by pfslam_step.  The per-frame collective count is
+    2, plus 1 in frames that resample."""
+    import json
+    assert pkg.device_count() > 0
+    build_host(pkg)
+    pts, segs = pkg.synth.make_map_points(20000, seed=1)
+    tree = pkg.kd_create(pts)
+    n_steps, n_warm = 14, 3
+    scans = np.stack([pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f) for f in range(n_steps + n_warm)]).astype(np.float32)
+    (tmp_path / "map.nodes").write_bytes(tree.tobytes())
+    scans.tofile(str(tmp_path / "scans.f32"))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PFSLAM_RANK"):
+        env.pop(k, None)
+    out = subprocess.check_output([os.path.join(HOST, "pfslam_mgpu"), "--gpus", "1", str(tmp_path / "map.nodes"), str(tmp_path / "scans.f32"),
+                                   str(particles), "--steps", str(n_steps), "--warmup", str(n_warm), "--first-frame", "6",
+                                   "--dump", str(tmp_path / "out")], env=env, timeout=300).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    h = pkg.PfSlam(particles, kd_capacity=len(tree) + (1 << 18))
+    h.set_map(tree)
+    for f in range(1, 6):
+        h.motion_update(f)
+    resampled = 0
+    for k in range(n_steps + n_warm):
+        h.step(6 + k, scans[k])
+        resampled += h.trace()["resampled"]
+    assert d["n_gpus"] == 1 and d["steps"] == n_steps and d["warmup"] == n_warm and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["particles_global"] == particles and d["config"]["kd_size_end"] == h.kd_size
+    assert d["config"]["collectives"] == 2 * (n_steps + n_warm) + resampled and resampled > 0
+    got = np.fromfile(str(tmp_path / "out.rank0.particles"), dtype=pkg.PARTICLE_DTYPE)
+    want = h.particles()
+    for fld in ("x", "y", "theta", "w"):
+        assert (got[fld].view(np.int32) == want[fld].view(np.int32)).all(), fld
+    assert (tmp_path / "out.rank0.nodes").read_bytes() == h.map().tobytes()
+    assert (np.array(d["config"]["pose"], np.float32).view(np.int32) == h.pose.view(np.int32)).all()
+    h.close()

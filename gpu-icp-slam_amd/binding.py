@@ -23,8 +23,8 @@ SYMBOLS = [
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
-    "pfslam_kd_create", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_score_census", "pfslam_ubench_gather",
+    "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_ubench_gather",
 ]
 
 
@@ -120,6 +120,8 @@ def load():
     L.pfslam_find_walls.argtypes = [vp, vp, vp, vp]
     L.pfslam_check_loop_closure.argtypes = [vp, vp, i32, vp]
     L.pfslam_get_topology.argtypes = [vp, vp, i32, vp, vp]
+    L.pfslam_set_topology.argtypes = [vp, i32]
+    L.pfslam_get_closures.argtypes = [vp, vp, i32, vp]
     L.pfslam_score_census.argtypes = [vp, vp]
     L.pfslam_ubench_gather.argtypes = [vp, vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
@@ -132,6 +134,7 @@ def load():
     L.pfslam_set_variant.argtypes = [vp, i32]
     L.pfslam_kd_create.argtypes = [vp, i32, vp]
     L.pfslam_kd_insert_node.argtypes = [vp, vp, i32]
+    L.pfslam_kd_insert_list.argtypes = [vp, i32, vp, i32, i32]
     L.pfslam_kd_balance.argtypes = [vp, i32]
     L.pfslam_debug_math.argtypes = [vp, i32, vp, i32, vp]
     L.pfslam_set_timing.argtypes = [vp, i32]
@@ -325,6 +328,16 @@ class PfSlam:
         pairs = np.zeros((cap, 2), np.int32)
         n = C.c_int()
         _chk(self.L.pfslam_check_loop_closure(self._h, _p(pairs), cap, C.byref(n)), "pfslam_check_loop_closure")
+        return pairs[:min(n.value, cap)].copy()
+
+    def set_topology(self, enable=True):
+        """UpdateTopology + CheckLoopClosure at the end of every step() / step_grid() (kernel.cu:1750-1751)."""
+        _chk(self.L.pfslam_set_topology(self._h, int(enable)), "pfslam_set_topology")
+
+    def closures(self, cap=65536):
+        pairs = np.zeros((cap, 2), np.int32)
+        n = C.c_int()
+        _chk(self.L.pfslam_get_closures(self._h, _p(pairs), cap, C.byref(n)), "pfslam_get_closures")
         return pairs[:min(n.value, cap)].copy()
 
     def topology(self, cap=4096):

@@ -59,6 +59,17 @@ extern "C" int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out)
     return 0;
 }
 
+// KDTree::InsertList (kdtree.cpp:46-67): the sub-tree of `n` points in pre-order at list[idx ...], hanging below `parent`
+// (split axis = parent's + 1; -1 = root).  Like the reference it does not touch the parent's child links.
+extern "C" int pfslam_kd_insert_list(const float *pts_xyzw, int n, pfslam_node *list, int idx, int parent)
+{
+    if (n <= 0 || !pts_xyzw || !list || idx < 0 || parent < -1) return 1;
+    std::vector<Pt> buf(n);
+    for (int i = 0; i < n; i++) buf[i] = Pt{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
+    build_range(buf, 0, n, list, idx, parent, 0);
+    return 0;
+}
+
 extern "C" int pfslam_kd_insert_node(const float p[4], pfslam_node *list, int list_size)
 {
     if (!p || !list || list_size <= 0) return 1;

@@ -20,6 +20,10 @@ void KDTree::Create(std::vector<glm::vec4> input, Node *list)
 {
     pfslam_kd_create(reinterpret_cast<const float *>(input.data()), (int)input.size(), reinterpret_cast<pfslam_node *>(list));
 }
+void KDTree::InsertList(std::vector<glm::vec4> input, Node *list, int idx, int parent)
+{
+    pfslam_kd_insert_list(reinterpret_cast<const float *>(input.data()), (int)input.size(), reinterpret_cast<pfslam_node *>(list), idx, parent);
+}
 void KDTree::InsertNode(glm::vec4 point, Node *list, int listSize)
 {
     const float p[4] = {point.x, point.y, point.z, point.w};
@@ -104,6 +108,11 @@ void Scene::parse_map_block(std::istream &in)
     m.uid = 0;
     maps.push_back(m);
 }
+static glm::vec3 v_normalize(const glm::vec3 &v) // glm::normalize: v * inversesqrt(dot(v, v)); the zero vector gives NaN
+{
+    const float inv = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return glm::vec3(v.x * inv, v.y * inv, v.z * inv);
+}
 void Scene::parse_camera_block(std::istream &in)
 {
     Camera &c = state.camera;
@@ -118,6 +127,21 @@ void Scene::parse_camera_block(std::istream &in)
         else if (t[0] == "LOOKAT" && t.size() >= 4) c.lookAt = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
         else if (t[0] == "UP" && t.size() >= 4) c.up = glm::vec3((float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str()));
     }
+    // derived fields, in the reference's order (scene.cpp:107-121): fov.x from the aspect ratio; `right` is computed from
+    // `view` BEFORE view is assigned (so from the zero vector here: NaN components, as normalize(0) gives) and is not used by
+    // the SLAM path; pixelLength; view; the image buffer sized to the resolution
+    const float PI_F = 3.1415926535897932384626422832795028841971f; // utilities.h:12
+    const float fovy = c.fov.y;
+    const float yscaled = tanf(fovy * (PI_F / 180));
+    const float xscaled = (yscaled * c.resolution.x) / c.resolution.y;
+    const float fovx = (atanf(xscaled) * 180) / PI_F;
+    c.fov = glm::vec2(fovx, fovy);
+    const glm::vec3 cr(c.view.y * c.up.z - c.view.z * c.up.y, c.view.z * c.up.x - c.view.x * c.up.z, c.view.x * c.up.y - c.view.y * c.up.x);
+    c.right = v_normalize(cr);
+    c.pixelLength = glm::vec2(2 * xscaled / (float)c.resolution.x, 2 * yscaled / (float)c.resolution.y);
+    c.view = v_normalize(glm::vec3(c.lookAt.x - c.position.x, c.lookAt.y - c.position.y, c.lookAt.z - c.position.z));
+    const int arraylen = c.resolution.x * c.resolution.y;
+    state.image.assign(arraylen > 0 ? (size_t)arraylen : 0, glm::vec3());
 }
 
 Pointcloud::Pointcloud(std::string filename)
@@ -139,6 +163,7 @@ static bool g_grid_map = false;
 static Scene *g_scene = nullptr;
 static int g_particles = 1000; // PARTICLE_COUNT, kernel.cu:30
 static glm::vec3 g_robotPos;
+static bool g_topology = false;
 
 void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line)
 {
@@ -166,6 +191,8 @@ void particleFilterInit(Scene *scene)
     }
     if (const char *e = getenv("PFSLAM_KD_CAPACITY")) cfg.kd_capacity = atoi(e);
     PFCHK(pfslam_create(&cfg, &g_handle), "particleFilterInit");
+    if (const char *e = getenv("PFSLAM_TOPOLOGY")) g_topology = atoi(e) != 0;
+    PFCHK(pfslam_set_topology(g_handle, g_topology ? 1 : 0), "particleFilterInit (topology)");
     g_robotPos = glm::vec3(0.0f);
     particleFilterInitPC();
 }
@@ -189,8 +216,63 @@ void particleFilter(uchar4 *, int frame, Lidar *lidar)
     else
         PFCHK(pfslam_step(g_handle, frame, lidar->scans[frame].data()), "particleFilter");
 }
+void particleFilterPC(int frame, Lidar *lidar)
+{
+    const bool grid = g_grid_map;
+    g_grid_map = false;
+    particleFilter(nullptr, frame, lidar);
+    g_grid_map = grid;
+}
 void pfslamUseGridMap(bool on) { g_grid_map = on; }
+void pfslamUseTopology(bool on)
+{
+    g_topology = on;
+    if (g_handle) PFCHK(pfslam_set_topology(g_handle, on ? 1 : 0), "pfslamUseTopology");
+}
+std::vector<std::pair<int, int>> pfslamLoopClosures()
+{
+    std::vector<std::pair<int, int>> out;
+    if (!g_handle) return out;
+    int n = 0;
+    PFCHK(pfslam_get_closures(g_handle, nullptr, 0, &n), "pfslamLoopClosures");
+    std::vector<int32_t> buf((size_t)2 * (n > 0 ? n : 1));
+    PFCHK(pfslam_get_closures(g_handle, buf.data(), n, &n), "pfslamLoopClosures");
+    for (int k = 0; k < n; k++) out.push_back(std::make_pair((int)buf[2 * k], (int)buf[2 * k + 1]));
+    return out;
+}
 void drawMap(uchar4 *) {}
+
+int pfslamExportMap(const char *prefix)
+{
+    if (!g_handle || !prefix) return -1;
+    const std::string base(prefix);
+    const pfslam_node *kd = nullptr;
+    const int8_t *grid = nullptr;
+    int nk = 0, dx = 0, dy = 0;
+    PFCHK(pfslam_get_map(g_handle, &kd, &nk), "pfslamExportMap map");
+    PFCHK(pfslam_get_grid(g_handle, &grid, &dx, &dy), "pfslamExportMap grid");
+    std::ofstream bin(base + ".kd.bin", std::ios::binary), csv(base + ".kd.csv");
+    csv << "x y z w\n";
+    int kept = 0;
+    char line[160];
+    for (int i = 0; i < nk; i++) {
+        if (!(kd[i].w > -100)) continue; // the viewer's filter, main.cpp:269
+        const float p[4] = {kd[i].x, kd[i].y, kd[i].z, kd[i].w};
+        bin.write(reinterpret_cast<const char *>(p), 16);
+        snprintf(line, sizeof(line), "%.9g %.9g %.9g %.9g\n", p[0], p[1], p[2], p[3]);
+        csv << line;
+        kept++;
+    }
+    std::ofstream(base + ".grid.i8", std::ios::binary).write(reinterpret_cast<const char *>(grid), (std::streamsize)dx * dy);
+    std::ofstream pgm(base + ".grid.pgm", std::ios::binary);
+    pgm << "P5\n" << dy << " " << dx << "\n255\n";
+    std::vector<unsigned char> row((size_t)dy);
+    for (int x = 0; x < dx; x++) {
+        for (int y = 0; y < dy; y++) row[y] = (unsigned char)((int)grid[(size_t)x * dx + y] + 128);
+        pgm.write(reinterpret_cast<const char *>(row.data()), dy);
+    }
+    return kept;
+}
 
 void getPCData(Particle **ptrParticles, MAP_TYPE **ptrMap, KDTree::Node **ptrKD, int *nParticles, int *nKD, glm::vec3 &pos)
 {

@@ -14,6 +14,7 @@ public:
 };
 static_assert(sizeof(Node) == 32, "KDTree::Node must stay 32 bytes");
 void Create(std::vector<glm::vec4> input, Node *list);
+void InsertList(std::vector<glm::vec4> input, Node *list, int idx, int parent);
 void InsertNode(glm::vec4 point, Node *list, int listSize);
 void Balance(Node *list, int listSize);
 } // namespace KDTree

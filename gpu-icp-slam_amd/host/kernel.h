@@ -18,6 +18,9 @@ void drawMap(uchar4 *pbo);
 void getPCData(Particle **ptrParticles, MAP_TYPE **ptrMap, KDTree::Node **ptrKD, int *nParticles, int *nKD, glm::vec3 &pos);
 void particleFilterInitPC();
 void particleFilterFreePC();
+// declared by the reference (kernel.h:24) but never defined there; here it is the point-cloud frame: particleFilter without
+// the unused pbo
+void particleFilterPC(int frame, Lidar *lidar);
 
 // PARTICLE_COUNT is a compile-time 1000 in the reference (kernel.cu:30); here it is a runtime setting read by the
 // next particleFilterInit (also: environment variable PFSLAM_PARTICLES).
@@ -26,6 +29,16 @@ void pfslamSetParticleCount(int n);
 // this selects which stages particleFilter() runs: false = KD point cloud (default), true = 2-D occupancy grid
 // (PFMeasurementUpdate / PFUpdateMap).  Also: environment variable PFSLAM_MAP=grid.
 void pfslamUseGridMap(bool on);
+// The reference has UpdateTopology() / CheckLoopClosure() commented out at the end of particleFilter (kernel.cu:1750-1751):
+// this enables them there (also: environment variable PFSLAM_TOPOLOGY=1).  pfslamLoopClosures returns the
+// (candidate node, visible node) pairs the last frame proposed.
+void pfslamUseTopology(bool on);
+std::vector<std::pair<int, int>> pfslamLoopClosures();
+// Map export for an end-to-end comparison: the point-cloud map as the reference's viewer filters it
+// (nodes with w > -100, main.cpp:269-284) -> PREFIX.kd.bin (float x, y, z, w per point, in node order) + PREFIX.kd.csv, and
+// the 2-D occupancy grid -> PREFIX.grid.i8 (dim.x * dim.y signed bytes, cell (x, y) at x * dim.x + y) + PREFIX.grid.pgm
+// (value + 128, one row per x).  Returns the number of exported points.
+int pfslamExportMap(const char *prefix);
 
 // error convention of the reference: print and exit (kernel.h:42-60)
 void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line);

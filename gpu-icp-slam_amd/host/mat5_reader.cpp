@@ -153,7 +153,13 @@ bool mat5_read_lidar_scans(const std::string &path, std::vector<std::vector<floa
     if (!f.is_open()) { err = "cannot open " + path; return false; }
     std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (file.size() < 128) { err = "not a MAT-file (shorter than its header)"; return false; }
-    if (!(file[126] == 'I' && file[127] == 'M')) { err = "only little-endian Level-5 MAT-files are supported"; return false; }
+    if (file[126] == 'M' && file[127] == 'I') { err = "big-endian MAT-file: only little-endian Level-5 MAT-files are supported"; return false; }
+    if (!(file[126] == 'I' && file[127] == 'M')) { err = "not a Level-5 MAT-file (no endian indicator in the header)"; return false; }
+    // version field 0x0200 (and the text "MATLAB 7.3 MAT-file"): an HDF5 container, not the Level-5 element stream
+    if ((file[124] == 0x00 && file[125] == 0x02) || memcmp(file.data(), "MATLAB 7.3", 10) == 0) {
+        err = "MATLAB v7.3 (HDF5) MAT-file: not supported, re-save with -v7 or convert with tools/mat2bin.py";
+        return false;
+    }
     Span s{file.data() + 128, file.size() - 128};
     std::vector<uint8_t> inflated;
     while (s.n >= 8) {

@@ -1,6 +1,7 @@
 // selftest.cpp -- no-GPU check of the C++ host layer: loaders and the KDTree facade.
 //   pfslam_host_selftest <scene.txt> <lidar.f32> <cloud.txt>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include "kernel.h"
 #include "pointcloud.h"
@@ -11,6 +12,11 @@ int main(int argc, char **argv)
     if (argc < 4) return 2;
     Scene scene(argv[1]);
     if (scene.maps.size() != 1) return 10;
+    {   // derived camera fields, in the reference's order (scene.cpp:107-121)
+        const Camera &c = scene.state.camera;
+        printf("camera fov %.6f %.6f pixel %.9f %.9f view %.6f %.6f %.6f right_is_nan %d image %zu\n", c.fov.x, c.fov.y, c.pixelLength.x,
+               c.pixelLength.y, c.view.x, c.view.y, c.view.z, (int)(c.right.x != c.right.x), scene.state.image.size());
+    }
     printf("map %.6f %.6f %.6f cam %d %d eye %.3f %.3f %.3f file %s\n", scene.maps[0].scale.x, scene.maps[0].scale.y,
            scene.maps[0].resolution.x, scene.state.camera.resolution.x, scene.state.camera.resolution.y,
            scene.state.camera.position.x, scene.state.camera.position.y, scene.state.camera.position.z,
@@ -33,6 +39,20 @@ int main(int argc, char **argv)
     KDTree::Balance(a.data(), 258);
     pfslam_kd_balance(b.data(), 258);
     if (memcmp(a.data(), b.data(), 258 * 32) != 0) return 12;
+    // KDTree::Create == sort on x + InsertList(input, list, 0, -1) (kdtree.cpp:25-29); and a sub-tree below an existing node
+    {
+        std::vector<glm::vec4> all;
+        for (int i = 0; i < 258; i++) all.push_back(a[i].value);
+        std::vector<KDTree::Node> viaCreate(300), viaList(300);
+        KDTree::Create(all, viaCreate.data());
+        std::sort(all.begin(), all.end(), [](const glm::vec4 &p, const glm::vec4 &q) { return p.x < q.x; });
+        KDTree::InsertList(all, viaList.data(), 0, -1);
+        if (memcmp(viaCreate.data(), viaList.data(), 258 * 32) != 0) return 13;
+        std::vector<glm::vec4> few;
+        for (int i = 0; i < 5; i++) few.push_back(glm::vec4(0.1f * i, 0.2f, 0.0f, 1.0f));
+        KDTree::InsertList(few, viaList.data(), 258, 0); // axis = parent's + 1 = y: all keys tie, mid = 2
+        if (viaList[258].axis != 1 || viaList[258].parent != 0 || viaList[258].left != 259 || viaList[258].right != 261) return 14;
+    }
     printf("kdtree ok root %d %d %d\n", a[0].axis, a[0].left, a[0].right);
     return 0;
 }

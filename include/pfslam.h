@@ -22,7 +22,7 @@
  *   pfslam_update_map_kd               PFUpdateMapKD                      kernel.cu:1406-1540
  *   pfslam_resample                    PFResample / kernWeightedSample    kernel.cu:420-511
  *   pfslam_score_grid/update_map_grid  kernEvaluateParticles / PFUpdateMap kernel.cu:243-372,513-621
- *   pfslam_kd_create/insert/balance    KDTree::Create/InsertNode/Balance  kdtree.cpp:25-105
+ *   pfslam_kd_create/insert_list/insert_node/balance   KDTree::Create/InsertList/InsertNode/Balance  kdtree.cpp:25-105
  *   pfslam_step_grid                   the frame loop of kernel.cu:1702-1762 with the 2-D stages
  *                                      PFMeasurementUpdate / PFUpdateMap  kernel.cu:307-339, 551-577
  *   pfslam_traverse                    findCorrespondenceIndexKD          kernel.cu:924-972
@@ -143,7 +143,8 @@ int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *bes
 
 /* ---- topology graph / loop-closure proposal (UpdateTopology, FindWalls, CheckLoopClosure: kernel.cu:623-795).
  * The reference leaves both calls commented out of its step (kernel.cu:1750-1751) and discards the clusters it builds
- * (kernel.cu:776), so these are explicit entry points, not part of pfslam_step.  They act on the current robot pose
+ * (kernel.cu:776), so they are explicit entry points, and part of the frame loops only after pfslam_set_topology(h, 1).
+ * They act on the current robot pose
  * and on the 2-D occupancy grid (pfslam_set_grid / pfslam_update_map_grid).
  * topology_update: adds a graph node when the pose is > 2.5 m from every node; *n_nodes receives the node count.
  * find_walls: cells with occupancy > 30 on the Bresenham ray between two world points (exact count; the reference's
@@ -151,6 +152,13 @@ int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *bes
  * check_loop_closure: pairs (candidate node j, visible node k) for every node j closer than 6 m on the map and
  *   farther than 20 m along the graph; returns the pair count in *n (pairs beyond cap are counted, not written).
  * get_topology: nodes as (x, y, dist) triples; *node_idx = index of the current node. */
+/* pfslam_set_topology(h, 1): pfslam_step and pfslam_step_grid then run UpdateTopology and CheckLoopClosure at the end of every
+ *   frame, exactly where the reference has the two calls commented out (kernel.cu:1750-1751); pfslam_get_closures returns the
+ *   pairs the LAST frame proposed (count in *n; pairs beyond cap are counted, not written).  In the KD frame loop FindWalls
+ *   reads the 2-D grid the KD path never updates (dev_occupancyGrid, kernel.cu:680: all -100, every node visible); in the 2-D
+ *   frame loop it reads the live map. */
+int pfslam_set_topology(pfslam_handle *h, int enable);
+int pfslam_get_closures(pfslam_handle *h, int32_t *pairs, int cap, int *n);
 int pfslam_topology_update(pfslam_handle *h, int *n_nodes);
 int pfslam_find_walls(pfslam_handle *h, const float a_xy[2], const float b_xy[2], int *n_walls);
 int pfslam_check_loop_closure(pfslam_handle *h, int32_t *pairs, int cap, int *n);
@@ -221,6 +229,8 @@ int pfslam_set_variant(pfslam_handle *h, int variant);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
 int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);
+/* KDTree::InsertList (kdtree.cpp:46-67): sub-tree of n points in pre-order at list[idx ...] below `parent` (-1: root) */
+int pfslam_kd_insert_list(const float *pts_xyzw, int n, pfslam_node *list, int idx, int parent);
 int pfslam_kd_insert_node(const float p[4], pfslam_node *list, int list_size);
 int pfslam_kd_balance(pfslam_node *list, int n);
 

@@ -102,6 +102,9 @@ def lib():
     L.orc_slam_step_grid.restype = None; L.orc_slam_step_grid.argtypes = [vp, i32, vp]
     L.orc_slam_step_grid_cpu.restype = None; L.orc_slam_step_grid_cpu.argtypes = [vp, i32, vp]
     L.orc_slam_set_grid.restype = None; L.orc_slam_set_grid.argtypes = [vp, vp]
+    L.orc_slam_set_topology.restype = None; L.orc_slam_set_topology.argtypes = [vp, i32]
+    L.orc_slam_last_closures.restype = i32; L.orc_slam_last_closures.argtypes = [vp, vp, i32]
+    L.orc_slam_topology.restype = vp; L.orc_slam_topology.argtypes = [vp]
     L.orc_slam_grid.restype = vp; L.orc_slam_grid.argtypes = [vp]
     L.orc_slam_set_particles.restype = None; L.orc_slam_set_particles.argtypes = [vp, vp]
     L.orc_slam_get_pose.restype = None; L.orc_slam_get_pose.argtypes = [vp, vp]
@@ -255,6 +258,19 @@ class Slam:
         """The reference's CPU branches of the 2-D frame loop (kernel.cu:340-369, 487-508, 578-620; H7)."""
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         lib().orc_slam_step_grid_cpu(self.h, frame, P(scan))
+
+    def set_topology(self, enable=True):
+        lib().orc_slam_set_topology(self.h, int(enable))
+
+    def closures(self, cap=65536):
+        pairs = np.zeros((cap, 2), np.int32)
+        n = lib().orc_slam_last_closures(self.h, P(pairs), cap)
+        return pairs[:min(n, cap)].copy()
+
+    def topology(self):
+        """(nodes as (x, y, dist) rows, index of the current node)"""
+        t = Topology.from_address(lib().orc_slam_topology(self.h))
+        return t.nodes(), t.node_idx
 
     def set_grid(self, grid):
         grid = np.ascontiguousarray(grid, dtype=np.int8)

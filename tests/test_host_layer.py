@@ -44,6 +44,60 @@ def test_loaders_and_kdtree_facade(tmp_path, pkg):
     assert "lidar 3 1081 0.000000 %.6f" % scans[-1, -1] in out
     assert "cloud 3 6 4 5 1" in out       # vec4(third, first, second, line index), pointcloud.cpp:22
     assert "kdtree ok root 0 1" in out
+    # derived camera fields, computed in the reference's order (scene.cpp:107-121): fov.x from the aspect ratio, pixelLength,
+    # view = normalize(lookAt - eye); `right` comes from the not-yet-assigned view there (NaN), the image buffer is RES.x * RES.y
+    cam = [l for l in out.splitlines() if l.startswith("camera ")][0].split()
+    assert np.allclose([float(v) for v in cam[2:4]], [45.0, 45.0], atol=1e-4) and np.allclose([float(v) for v in cam[5:7]], 2.0 / 800, rtol=1e-6)
+    assert [float(v) for v in cam[8:11]] == [0.0, 0.0, -1.0] and cam[12] == "1" and cam[14] == "640000"
+
+
+@pytest.mark.parametrize("kind", ["v73", "big_endian", "truncated", "short", "not_cell", "odd_size_f32"])
+def test_lidar_loader_failure_paths(tmp_path, pkg, kind):
+    """Unsupported or damaged lidar files end with a message that says what is wrong (the reference prints and `throw`s,
+    lidar.cpp:20-24): MATLAB v7.3 / HDF5 containers, big-endian files, truncated element streams, files shorter than the
+    header, a `lidar` variable that is not a cell array, and flat float32 files whose size is not frames x 1081."""
+    sio = pytest.importorskip("scipy.io")
+    build_host(pkg)
+    scene = tmp_path / "scene.txt"
+    scene.write_text(SCENE_TXT)
+    cloud = tmp_path / "cloud.txt"
+    cloud.write_text("1 2 3\n4 5 6\n")
+    good = tmp_path / "good.mat"
+    cells = np.empty((1, 3), dtype=object)
+    for i in range(3):
+        cells[0, i] = {"scan": np.full((1, 1081), float(i), np.float32)}
+    sio.savemat(str(good), {"lidar": cells}, do_compression=False)
+    raw = bytearray(good.read_bytes())
+    path = tmp_path / ("bad_%s.mat" % kind)
+    want = None
+    if kind == "v73":
+        hdr = b"MATLAB 7.3 MAT-file, Platform: GLNXA64, Created on: Mon Jan  1 00:00:00 2024 HDF5 schema 1.00 ."
+        raw[:116] = hdr.ljust(116, b" ")
+        raw[124:126] = bytes([0x00, 0x02])
+        raw[128:136] = b"\x89HDF\r\n\x1a\n"
+        want = "v7.3"
+    elif kind == "big_endian":
+        raw[124:128] = bytes([0x01, 0x00]) + b"MI"
+        want = "big-endian"
+    elif kind == "truncated":
+        raw = raw[:len(raw) // 2]
+        want = "corrupt"
+    elif kind == "short":
+        raw = raw[:100]
+        want = "shorter than its header"
+    elif kind == "not_cell":
+        sio.savemat(str(path), {"lidar": np.arange(10.0)}, do_compression=False)
+        raw = None
+        want = "not a cell array"
+    elif kind == "odd_size_f32":
+        path = tmp_path / "odd.f32"
+        raw = bytearray(b"\0" * (1081 * 4 + 12))
+        want = "neither .mat nor frames x 1081"
+    if raw is not None:
+        path.write_bytes(bytes(raw))
+    r = subprocess.run([os.path.join(HOST, "pfslam_host_selftest"), str(scene), str(path), str(cloud)], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert want in (r.stdout + r.stderr), (kind, r.stdout[-400:], r.stderr[-400:])
 
 
 @pytest.mark.gpu

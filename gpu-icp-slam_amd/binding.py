@@ -24,7 +24,7 @@ SYMBOLS = [
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_ubench_gather",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_ubench_gather", "pfslam_plan_stats",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
     L.pfslam_get_closures.argtypes = [vp, vp, i32, vp]
     L.pfslam_score_census.argtypes = [vp, vp]
     L.pfslam_ubench_gather.argtypes = [vp, vp]
+    L.pfslam_plan_stats.argtypes = [vp, vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -348,9 +349,16 @@ class PfSlam:
 
     def score_census(self):
         """One counting launch of the score kernel on the current state (see include/pfslam.h)."""
-        out = (C.c_ulonglong * 4)()
+        out = (C.c_ulonglong * 8)()
         _chk(self.L.pfslam_score_census(self._h, out), "pfslam_score_census")
-        return {"trips": int(out[0]), "visits": int(out[1]), "tests": int(out[2]), "test_lanes": int(out[3])}
+        return {"trips": int(out[0]), "visits": int(out[1]), "tests": int(out[2]), "test_lanes": int(out[3]),
+                "uniform_trips": int(out[4]), "prefix_trips": int(out[5]), "redescents": int(out[6]), "redescents_noop": int(out[7])}
+
+    def plan_stats(self):
+        out = (C.c_double * 10)()
+        _chk(self.L.pfslam_plan_stats(self._h, out), "pfslam_plan_stats")
+        keys = ("rows", "path_len", "candidates", "frac_complete", "frac_no_plan", "frac_full", "box_dx", "box_dy", "box_dtheta", "waves")
+        return dict(zip(keys, [float(v) for v in out]))
 
     def ubench_gather(self):
         out = (C.c_double * 4)()

@@ -26,6 +26,10 @@ struct KdCensus {
     unsigned long long lanes;        // active lanes summed over those trips = node visits
     unsigned long long tests;        // wave-level parent-hyperplane tests (each: one 4-byte + one 16-byte wave gather)
     unsigned long long test_lanes;   // lanes in them
+    unsigned long long uniform;      // descent-loop trips in which every active lane stood on the same node
+    unsigned long long prefix;       // ... and all 64 lanes were still on the common path from the root (first descent only)
+    unsigned long long redesc;       // re-descents started (lanes)
+    unsigned long long redesc_noop;  // ... that left the best node unchanged
 };
 
 // In a planar map a z-level node (axis 2) always sends the query right (0 < 0 is false).  Its hot record therefore
@@ -78,7 +82,7 @@ __device__ int kd_load_i32(kd_rsrc_t r, int idx);
 
 // Per-lane census counters (registers): a wave-level event is booked on its first active lane, every active lane books
 // itself; census_flush adds a wave's totals to the global record once, at the end of the kernel.
-struct KdCensusLocal { unsigned trips, lanes, tests, test_lanes; };
+struct KdCensusLocal { unsigned trips, lanes, tests, test_lanes, uniform, prefix, redesc, redesc_noop; };
 __device__ __forceinline__ void census_add(unsigned &ev, unsigned &lanes)
 {
     const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -87,14 +91,18 @@ __device__ __forceinline__ void census_add(unsigned &ev, unsigned &lanes)
 }
 __device__ __forceinline__ void census_flush(const KdCensusLocal &c, KdCensus *out)
 {
-    unsigned long long v[4] = {c.trips, c.lanes, c.tests, c.test_lanes};
-    for (int k = 0; k < 4; k++)
+    unsigned long long v[8] = {c.trips, c.lanes, c.tests, c.test_lanes, c.uniform, c.prefix, c.redesc, c.redesc_noop};
+    for (int k = 0; k < 8; k++)
         for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out->trips, v[0]);
         atomicAdd(&out->lanes, v[1]);
         atomicAdd(&out->tests, v[2]);
         atomicAdd(&out->test_lanes, v[3]);
+        atomicAdd(&out->uniform, v[4]);
+        atomicAdd(&out->prefix, v[5]);
+        atomicAdd(&out->redesc, v[6]);
+        atomicAdd(&out->redesc_noop, v[7]);
     }
 }
 
@@ -111,16 +119,29 @@ __device__ __forceinline__ void census_flush(const KdCensusLocal &c, KdCensus *o
 // H1: the reference reads tree[-1] when the best node is the root; here the search stops.
 #define PF_GUARD_K 0.999999523162841796875f /* 1 - 2^-21 */
 
+// kd_resume continues a traversal from the state (sBest, bestIdx, head) of its FIRST descent: the score kernel enters here
+// after it has worked off the part of the root path that the whole wave shares (see KdPlan below); head < 0 = the first
+// descent is already complete.  kd_nearest_ref is the whole traversal: resume from the root with nothing seen.
 template <bool PLANAR, bool CENSUS = false>
-__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, KdCensusLocal *census = nullptr)
+__device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, float pz, float sBest, int bestIdx, int head,
+                                         KdCensusLocal *census = nullptr)
 {
-    // bestDist starts as the distance to the root; visiting the root first reproduces that state
-    float sBest = INFINITY;
-    int bestIdx = 0, prevBest = -1, head = 0;
+    int prevBest = -1;
     const kd_rsrc_t hot_rsrc = kd_rsrc(t.hot), parent_rsrc = kd_rsrc(t.parent);
+    bool on_prefix = head == 0; // census only: trips on the common path of all 64 lanes from the root
+    bool in_redesc = false;     // census only
     for (;;) {
         while (head >= 0) { // greedy descent
-            if (CENSUS) census_add(census->trips, census->lanes);
+            if (CENSUS) {
+                census_add(census->trips, census->lanes);
+                const unsigned long long ex = __builtin_amdgcn_read_exec();
+                const bool uni = __builtin_amdgcn_ballot_w64(head != __builtin_amdgcn_readfirstlane(head)) == 0ull;
+                on_prefix = on_prefix && uni && ex == ~0ull;
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+                    census->uniform += uni ? 1u : 0u;
+                    census->prefix += on_prefix ? 1u : 0u;
+                }
+            }
             const uint4 nd = kd_load_hot(hot_rsrc, head);
             // (node - query) as a 2-vector: v_pk_add_f32 / v_pk_mul_f32, one rounding per component as in the scalar form
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -164,6 +185,8 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
             head = lt ? left : (int)nd.w;
         }
         // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
+        on_prefix = false;
+        if (CENSUS && in_redesc && bestIdx == prevBest) census->redesc_noop++;
         if (bestIdx == prevBest) break;
         if (CENSUS) census_add(census->tests, census->test_lanes);
         prevBest = bestIdx;
@@ -193,9 +216,49 @@ __device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float p
         }
         if (!(hd < bestDist)) break;
         head = lt ? (int)nd.w : left; // the side the query is NOT on
+        if (CENSUS) {
+            in_redesc = true;
+            census->redesc++;
+        }
     }
     return bestIdx;
 }
+
+template <bool PLANAR, bool CENSUS = false>
+__device__ __forceinline__ int kd_nearest_ref(const KdView &t, float px, float py, float pz, KdCensusLocal *census = nullptr)
+{
+    // bestDist starts as the distance to the root; visiting the root first reproduces that state
+    return kd_resume<PLANAR, CENSUS>(t, px, py, pz, INFINITY, 0, 0, census);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Shared-prefix plan of the score kernel (planar maps).
+//
+// The 64 lanes of a wave score the SAME beam from 64 neighbouring poses (Hilbert order), so their queries lie in a box W a
+// few centimetres wide, and -- measured by pfslam_score_census -- 75-95 % of all descent-loop trips are spent on nodes that
+// every lane of the wave visits, in the same order: the root path, until W first straddles a split plane.  The first
+// descent of the reference traversal leaves best = the FIRST node of the path with the minimal (rounded) distance, nothing
+// else of the path matters.  So, once per (wave, beam), ONE lane of a small planning kernel walks that common root path and
+//   * stops where W straddles a split plane (`resume` = that node; -1 = the path was common down to the leaf), and
+//   * keeps of the path only the nodes that can be the nearest one for SOME point of W: node i is dropped when its smallest
+//     possible squared distance to W exceeds the largest possible squared distance of another path node, with a 1e-5 relative
+//     margin on either side (>> the 2^-21 guard band, >> float rounding) -- a dropped node is then strictly farther than
+//     that other node for every lane, so it can be neither the minimum nor tie with it.  Order is kept.
+// The score kernel then evaluates, per lane, only the few surviving candidates (from scalar registers: no gather, no child
+// selection, no loop divergence) with exactly the per-visit arithmetic of kd_resume, and continues per lane from `resume`.
+// Results are bit-identical to the plain traversal by construction; tests compare both against the oracle.
+// ------------------------------------------------------------------------------------------------------------------
+#define PF_PLAN_CAND 7 /* candidates per row: 128-byte rows */
+struct KdPlanRow {
+    int n_cand;     // candidates below (path order)
+    int resume;     // node at which the per-lane traversal continues, -1 = first descent complete
+    int path_len;   // nodes of the common root path (statistics)
+    float range;    // scan[beam]: rides along so that the score kernel needs one scalar stream only
+    float4 cand[PF_PLAN_CAND]; // {x, y, node index bits, lower bound (planning scratch)}
+};
+static_assert(sizeof(KdPlanRow) == 16 + 16 * PF_PLAN_CAND, "plan row layout");
+
+struct KdGroupBox { float xlo, xhi, ylo, yhi, tlo, thi; int count, pad; }; // pose bounding box of a wave's 64 particles
 
 // LIDAR_ANGLE(i) (kernel.cu:42) + CleanLidarScan (kernel.cu:182-187)
 __device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)

@@ -143,6 +143,7 @@ struct pfslam_handle {
     uint8_t *d_upd = nullptr, *h_upd = nullptr;
     size_t upd_bytes = 0;
     float *h_scan = nullptr; // pinned staging of the scan
+    float scan_reach = 8.0f; // mean in-range beam length of the current scan (m): the lever arm of a heading difference
     std::vector<pfslam_particle> h_particles;
     std::vector<float> h_tmp;
     int32_t trace[8] = {0};
@@ -167,6 +168,10 @@ struct pfslam_handle {
     double timer_ms[PF_TIMER_SLOTS] = {0};
     long timer_count[PF_TIMER_SLOTS] = {0};
     pf::KdCensus *d_census = nullptr;
+    // shared-prefix plan of the score kernel: one row per (wave of 64 lanes, beam), pose box per wave
+    pf::KdPlanRow *plan = nullptr;
+    size_t plan_rows = 0;
+    pf::KdGroupBox *group_box = nullptr;
 };
 
 // ==========================================================================================
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     const int i = order ? order[slot] : slot;
     const float x = px[i], y = py[i], th = pth[i];
     float acc = 0.0f;
-    pf::KdCensusLocal cl = {0, 0, 0, 0};
+    pf::KdCensusLocal cl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = j0; j < j1; j++) {
         float wx, wy;
         pf::clean_lidar_scan(j, scan[j], th, wx, wy);
@@ -226,6 +231,173 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
             const int b = pf::kd_nearest_ref<PLANAR, CENSUS>(tree, wx, wy, 0.0f, &cl);
             acc += tree.w[b];
         }
+    }
+    if (CENSUS) pf::census_flush(cl, census);
+    out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
+}
+
+// ---- shared-prefix plan (kd_device.h "Shared-prefix plan") ------------------------------------------------------
+// pose bounding box of every group of 64 lanes (= one wave of the score kernel)
+__global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, const float *__restrict__ py, const float *__restrict__ pth,
+                                                  int n, const int *__restrict__ order, pf::KdGroupBox *__restrict__ box)
+{
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const bool in = slot < n;
+    const int i = in ? (order ? order[slot] : slot) : 0;
+    const float x = in ? px[i] : 0.0f, y = in ? py[i] : 0.0f, t = in ? pth[i] : 0.0f;
+    float xlo = in ? x : INFINITY, xhi = in ? x : -INFINITY, ylo = in ? y : INFINITY, yhi = in ? y : -INFINITY;
+    float tlo = in ? t : INFINITY, thi = in ? t : -INFINITY;
+    for (int off = 32; off >= 1; off >>= 1) {
+        xlo = fminf(xlo, __shfl_xor(xlo, off, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, off, 64));
+        ylo = fminf(ylo, __shfl_xor(ylo, off, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, off, 64));
+        tlo = fminf(tlo, __shfl_xor(tlo, off, 64)); thi = fmaxf(thi, __shfl_xor(thi, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        // a NaN pose poisons min / max silently (fminf ignores NaN): such a group gets no plan
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(in && !(x == x && y == y && t == t));
+        pf::KdGroupBox b{xlo, xhi, ylo, yhi, tlo, thi, min(64, n - (int)blockIdx.x * 64), 0};
+        if (bad != 0ull) b.xlo = b.xhi = NAN;
+        box[blockIdx.x] = b;
+    }
+}
+
+// One lane per (group, beam): the common root path of the wave's 64 queries, pruned to the possible nearest nodes.
+// Every bound is conservative: W contains every lane's float-computed beam end point with >= 1e-4 m to spare.
+// The 64 lanes of a planning wave are 64 CONSECUTIVE GROUPS looking along the SAME beam: Hilbert neighbours, so their boxes
+// nearly coincide and the lanes walk the same nodes (coherent gathers, no loop divergence) -- with lanes = beams of one group
+// the same kernel took 0.45 ms instead of ~0.03.  The running candidate list lives in LDS (node index + lower bound).
+__global__ __launch_bounds__(64) void k_plan(const pf::KdGroupBox *__restrict__ box, int groups, const float *__restrict__ scan, int nb,
+                                             pf::KdView tree, pf::KdPlanRow *__restrict__ plan)
+{
+    __shared__ int s_idx[PF_PLAN_CAND][64];
+    __shared__ float s_lb[PF_PLAN_CAND][64];
+    const int lane = threadIdx.x, g = blockIdx.x * 64 + lane, j = blockIdx.y;
+    if (g >= groups) return;
+    pf::KdPlanRow *row = plan + ((size_t)g * nb + j);
+    const pf::KdGroupBox b = box[g];
+    const float r = scan[j];
+    const float tc = 0.5f * (b.tlo + b.thi), dth = 0.5f * (b.thi - b.tlo);
+    // egocentric end point at the centre heading (the lanes' own formula).  d/dphi of (r cos phi, r sin phi) is
+    // (-r sin phi, r cos phi), and |sin|, |cos| are 1-Lipschitz: over the group's headings the end point moves by at most
+    // (|cy| + |r| d) d in x and (|cx| + |r| d) d in y; eps covers the lanes' float rounding and the 1-ulp sincos many times over
+    float cx, cy;
+    pf::clean_lidar_scan(j, r, tc, cx, cy);
+    const float dd = dth + 1e-6f, eps = 2e-4f + 1e-5f * fabsf(r);
+    const float hx = (fabsf(cy) + fabsf(r) * dd) * dd + eps, hy = (fabsf(cx) + fabsf(r) * dd) * dd + eps;
+    const float wxlo = b.xlo + cx - hx, wxhi = b.xhi + cx + hx, wylo = b.ylo + cy - hy, wyhi = b.yhi + cy + hy;
+    int n_cand = 0, resume = 0, path_len = 0;
+    float U = INFINITY; // upper bound (with margin) of the final minimum for every point of W
+    // no plan (every lane walks from the root): non-finite or absurd geometry, NaN poses
+    const bool usable = (wxlo == wxlo) && (wxhi == wxhi) && (wylo == wylo) && (wyhi == wyhi) && fabsf(wxlo) < 1e6f && fabsf(wxhi) < 1e6f &&
+                        fabsf(wylo) < 1e6f && fabsf(wyhi) < 1e6f && (wxhi - wxlo) < 4.0f && (wyhi - wylo) < 4.0f;
+    if (usable) {
+        int head = 0;
+        while (head >= 0) {
+            const uint4 nd = tree.hot[head];
+            const float nx = __uint_as_float(nd.x), ny = __uint_as_float(nd.y);
+            const uint32_t axis = nd.z >> 30;
+            // does W lie entirely on one side of the split plane?  lanes go left iff q < node (strictly)
+            const float lo = axis == 0 ? wxlo : wylo, hi = axis == 0 ? wxhi : wyhi, v = axis == 0 ? nx : ny;
+            const bool all_left = hi < v, all_right = lo >= v;
+            if (axis < 2 && !(all_left || all_right)) break; // W straddles: lanes part here -> resume at this node
+            // squared distance range of W to the node
+            const float dxn = fmaxf(fmaxf(wxlo - nx, nx - wxhi), 0.0f), dyn = fmaxf(fmaxf(wylo - ny, ny - wyhi), 0.0f);
+            const float dxf = fmaxf(fabsf(nx - wxlo), fabsf(nx - wxhi)), dyf = fmaxf(fabsf(ny - wylo), fabsf(ny - wyhi));
+            const float lb = (dxn * dxn + dyn * dyn) * 0.99999f, ub = (dxf * dxf + dyf * dyf) * 1.00001f;
+            U = fminf(U, ub);
+            if (lb <= U) { // may be the nearest for some lane
+                if (n_cand == PF_PLAN_CAND) { // full: drop what the tighter U has ruled out meanwhile
+                    int m = 0;
+                    for (int k = 0; k < PF_PLAN_CAND; k++) {
+                        const int ci = s_idx[k][lane];
+                        const float cl = s_lb[k][lane];
+                        if (cl <= U) {
+                            s_idx[m][lane] = ci;
+                            s_lb[m][lane] = cl;
+                            m++;
+                        }
+                    }
+                    n_cand = m;
+                    if (n_cand == PF_PLAN_CAND) break; // still full: the lanes take over at this node
+                }
+                s_idx[n_cand][lane] = head;
+                s_lb[n_cand][lane] = lb;
+                n_cand++;
+            }
+            path_len++;
+            head = (axis < 2 && all_left) ? pf::hot_left(nd.z) : (int)nd.w; // planar z levels: both links hold the right child
+        }
+        resume = head;
+    }
+    int m = 0; // final pruning with the final U; the survivors' coordinates come from the map again (a few per row)
+    for (int k = 0; k < n_cand; k++) {
+        const int ci = s_idx[k][lane];
+        if (s_lb[k][lane] <= U) {
+            const uint4 nd = tree.hot[ci];
+            row->cand[m++] = make_float4(__uint_as_float(nd.x), __uint_as_float(nd.y), __int_as_float(ci), 0.0f);
+        }
+    }
+    row->n_cand = m;
+    row->resume = resume;
+    row->path_len = path_len;
+    row->range = r;
+}
+
+// The score kernel on a plan: per beam, every lane evaluates the wave's few candidate nodes out of scalar registers (the row
+// is wave-uniform), with the per-visit arithmetic of kd_resume, then continues per lane from the row's resume node.
+// The row of the NEXT beam (and its range) is requested before the current beam is worked on: rows are streamed once from
+// HBM / L2, and a wave that waited for its row on demand spent more time waiting than computing.
+__device__ __forceinline__ void plan_visit(const float4 cd, float wx, float wy, float &sBest, int &bestIdx)
+{
+    const float dx = cd.x - wx, dy = cd.y - wy;
+    const float s = dx * dx + dy * dy;
+    const float sGuard = sBest * PF_GUARD_K;
+    bool take = s < sGuard;
+    const bool inBand = (s < sBest) != take;
+    if (__builtin_amdgcn_ballot_w64(inBand) != 0ull) {
+        float sb = sBest;
+        asm volatile("" : "+v"(sb));
+        take = take | (inBand && pf::fsqrt(s) < pf::fsqrt(sb));
+    }
+    sBest = take ? s : sBest;
+    bestIdx = take ? __float_as_int(cd.z) : bestIdx;
+}
+
+template <bool CENSUS = false>
+__global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ px, const float *__restrict__ py,
+                                                      const float *__restrict__ pth, int n, const float *__restrict__ scan, int nb,
+                                                      int beams_per_chunk, pf::KdView tree, const pf::KdPlanRow *__restrict__ plan,
+                                                      const int *__restrict__ order, int direct, float *__restrict__ out,
+                                                      pf::KdCensus *__restrict__ census = nullptr)
+{
+    const int g = blockIdx.x, slot = g * 64 + threadIdx.x;
+    const int j0 = blockIdx.y * beams_per_chunk;
+    const int j1 = min(nb, j0 + beams_per_chunk);
+    if (slot >= n) return;
+    const int i = order ? order[slot] : slot;
+    const float x = px[i], y = py[i], th = pth[i];
+    float acc = 0.0f;
+    pf::KdCensusLocal cl = {0, 0, 0, 0, 0, 0, 0, 0};
+    const pf::KdPlanRow *rows = plan + (size_t)g * nb; // wave-uniform addresses: scalar loads
+    pf::KdPlanRow cur = rows[j0];
+    for (int j = j0; j < j1; j++) {
+        const pf::KdPlanRow nxt = rows[min(j + 1, j1 - 1)]; // in flight while this beam is scored
+        float wx, wy;
+        pf::clean_lidar_scan(j, cur.range, th, wx, wy);
+        if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
+            wx += x;
+            wy += y;
+            float sBest = INFINITY;
+            int bestIdx = 0;
+            const int nc = cur.n_cand;
+#pragma unroll
+            for (int c = 0; c < PF_PLAN_CAND; c++)
+                if (c < nc) plan_visit(cur.cand[c], wx, wy, sBest, bestIdx); // wave-uniform branch
+            if (CENSUS) cl.prefix += (unsigned)nc; // candidate evaluations (per lane)
+            const int b = pf::kd_resume<true, CENSUS>(tree, wx, wy, 0.0f, sBest, bestIdx, cur.resume, &cl);
+            acc += tree.w[b];
+        }
+        cur = nxt;
     }
     if (CENSUS) pf::census_flush(cl, census);
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
@@ -271,14 +443,14 @@ __device__ __forceinline__ unsigned spread10(unsigned v)
     return v;
 }
 __global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ x, const float *__restrict__ y,
-                                                     const float *__restrict__ th, int n, const float *__restrict__ pose,
+                                                     const float *__restrict__ th, int n, const float *__restrict__ pose, float reach,
                                                      unsigned *__restrict__ key, int *__restrict__ idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float qx = fminf(fmaxf((x[i] - pose[0]) * 500.0f + 512.0f, 0.0f), 1023.0f);
     const float qy = fminf(fmaxf((y[i] - pose[1]) * 500.0f + 512.0f, 0.0f), 1023.0f);
-    const float qt = fminf(fmaxf((th[i] - pose[2]) * 1000.0f + 512.0f, 0.0f), 1023.0f);
+    const float qt = fminf(fmaxf((th[i] - pose[2]) * 500.0f * reach + 512.0f, 0.0f), 1023.0f); // 2 mm of end-point travel per cell
     // Hilbert curve index (Skilling's axes-to-transpose, 10 bits x 3): unlike the plain bit interleave (Morton / Z-order) it has
     // no long jumps, so 64 consecutive particles are always neighbours -- worth 1 % of the score kernel (2.38 vs 2.40 ms)
     unsigned X[3] = {(unsigned)qt, (unsigned)qx, (unsigned)qy};
@@ -327,8 +499,10 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// reach: metres per radian -- a heading difference d moves a beam end point by ~ reach * d, so one cell is equally wide in x, y
+// and reach * theta (what makes the 64 queries of a wave a small box, see the shared-prefix plan)
 __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x, const float *__restrict__ y,
-                                                    const float *__restrict__ th, int n, unsigned *__restrict__ cell,
+                                                    const float *__restrict__ th, int n, float reach, unsigned *__restrict__ cell,
                                                     int *__restrict__ hist)
 {
     __shared__ float red[4];
@@ -342,10 +516,12 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
         const float a = x[k] - mx, b = y[k] - my, c = th[k] - mt;
         vx += a * a; vy += b * b; vt += c * c;
     }
-    // 64 cells over +-3.2 sigma: cell = 0.1 sigma, never finer than 0.25 mm / 0.125 mrad
-    const float cx = 1.0f / fmaxf(0.1f * sqrtf(block_sum_256(vx, red) * inv), 2.5e-4f);
-    const float cy = 1.0f / fmaxf(0.1f * sqrtf(block_sum_256(vy, red) * inv), 2.5e-4f);
-    const float ct = 1.0f / fmaxf(0.1f * sqrtf(block_sum_256(vt, red) * inv), 1.25e-4f);
+    // 64 cells over +-3.2 sigma of the widest dimension in the common metric (x, y, reach * theta): cell = 0.1 sigma of it,
+    // never finer than 0.25 mm
+    const float dev_x = sqrtf(block_sum_256(vx, red) * inv), dev_y = sqrtf(block_sum_256(vy, red) * inv);
+    const float dev_t = sqrtf(block_sum_256(vt, red) * inv) * reach;
+    const float e = fmaxf(0.1f * fmaxf(fmaxf(dev_x, dev_y), dev_t), 2.5e-4f);
+    const float cx = 1.0f / e, cy = 1.0f / e, ct = reach / e;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     unsigned X[3] = {(unsigned)fminf(fmaxf((th[i] - mt) * ct + 32.0f, 0.0f), 63.0f),
@@ -656,6 +832,8 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->phase_ev) (void)hipEventDestroy(h->phase_ev);
     if (h->d_census) (void)hipFree(h->d_census);
+    if (h->plan) (void)hipFree(h->plan);
+    if (h->group_box) (void)hipFree(h->group_box);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -825,10 +1003,26 @@ extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, 
     return 0;
 }
 
+// mean length of the beams that can score (finite, inside the +-20 m reject in at least one heading): performance hint only
+static void scan_reach_of(pfslam_handle *h, const float *scan)
+{
+    double sum = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < h->nb; j++) {
+        const float r = fabsf(scan[j]);
+        if (r < 28.3f) { // 20 * sqrt(2); NaN fails the compare
+            sum += r;
+            cnt++;
+        }
+    }
+    h->scan_reach = cnt ? (float)std::min(std::max(sum / cnt, 0.5), 30.0) : 8.0f;
+}
+
 extern "C" int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_beams)
 {
     if (!h || !scan_host || n_beams != h->nb) return fail("pfslam_set_scan: n_beams must equal cfg.n_beams");
     HIPCHK(hipSetDevice(h->cfg.device));
+    scan_reach_of(h, scan_host);
     HIPCHK(hipMemcpyAsync(h->scan, scan_host, (size_t)n_beams * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream)); // scan_host is pageable: do not return before it is consumed
     return 0;
@@ -959,15 +1153,16 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // default up to 400 k particles: counting sort over Hilbert cells of the cloud (3 launches; step 2.58 vs 2.61 ms at 100 k,
     // 0.477 vs 0.496 ms at 10 k).  Beyond that several particles share a cell and the full sort's finer order wins
     // (1 M particles: 22.55 vs 22.67 ms).
+    static const float theta_weight = getenv("PFSLAM_THETA_WEIGHT") ? (float)atof(getenv("PFSLAM_THETA_WEIGHT")) : 1.0f;
     if (h->variant != 1 && h->variant != 6 && h->n > 64 && h->n <= 400000) {
-        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->mkey, h->cells);
+        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan_reach * theta_weight, h->mkey, h->cells);
         hipLaunchKernelGGL(k_cell_scan, dim3(PF_CELLS / 1024), dim3(256), 0, h->stream, h->cells, h->cells + PF_CELLS, h->cells + 2 * PF_CELLS);
         hipLaunchKernelGGL(k_cell_scatter, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->mkey, h->n, h->cells + PF_CELLS,
                            h->cells + 2 * PF_CELLS, h->order2);
         HIPCHK(hipGetLastError());
         order = h->order2;
     } else if (h->variant != 1 && h->n > 64) { // large N, or variant 6 (A/B): 30-bit Hilbert keys + radix sort; variant 1 = identity order
-        hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose,
+        hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose, h->scan_reach * theta_weight,
                            h->mkey, h->order);
         size_t tb = h->sort_tmp_bytes;
         if (pfslam_sort_pairs_u32(h->sort_tmp, &tb, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, h->stream))
@@ -984,7 +1179,32 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
     // (2.387 vs 2.400 ms with 256-thread groups)
     const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
-    if (h->planar && census)
+    // Shared-prefix plan (planar maps; variant 2 = off, the plain per-lane traversal, for A/B): pose box of every wave, then one
+    // planning lane per (wave, beam).  Below ~2 k particles the waves' boxes are too wide for the plan to pay for its launches.
+    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 2048;
+    const bool use_plan = h->planar && h->variant != 2 && h->n >= plan_min_n;
+    if (use_plan) {
+        const int groups = (h->n + 63) / 64;
+        const size_t rows = (size_t)groups * h->nb;
+        if (rows > h->plan_rows) {
+            if (h->plan) HIPCHK(hipFree(h->plan));
+            if (h->group_box) HIPCHK(hipFree(h->group_box));
+            h->plan = nullptr;
+            h->group_box = nullptr;
+            CHK(dalloc(&h->plan, rows));
+            CHK(dalloc(&h->group_box, (size_t)groups));
+            h->plan_rows = rows;
+        }
+        hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box);
+        hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
+                           (const float *)h->scan, h->nb, kd_view(h), h->plan);
+        if (census)
+            hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                               kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, census);
+        else
+            hipLaunchKernelGGL((k_score_kd_plan<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                               kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, (pf::KdCensus *)nullptr);
+    } else if (h->planar && census)
         hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
                            kd_view(h), order, direct, out, census);
     else if (census)
@@ -1033,8 +1253,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
 // What one launch of the score kernel issues on the handle's current particles, scan and map: the counting instantiation
 // of the same kernel (same launch shape and lane order) -> out[0] wave-level trips of the descent loop (= wave-level 16-byte
 // gathers of node records), out[1] active lanes in them (= node visits), out[2] wave-level parent-hyperplane tests (each one
-// 4-byte and one 16-byte wave gather), out[3] lanes in them.  fit[] is recomputed (identical values).
-extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[4])
+// 4-byte and one 16-byte wave gather), out[3] lanes in them, out[4] trips in which every active lane stood on the same node,
+// out[5] those of them on the common path of all 64 lanes from the root.  fit[] is recomputed (identical values).
+extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[8])
 {
     if (!h || !out) return fail("pfslam_score_census: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1044,7 +1265,7 @@ extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[4])
     pf::KdCensus c;
     HIPCHK(hipMemcpyAsync(&c, h->d_census, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    out[0] = c.trips; out[1] = c.lanes; out[2] = c.tests; out[3] = c.test_lanes;
+    out[0] = c.trips; out[1] = c.lanes; out[2] = c.tests; out[3] = c.test_lanes; out[4] = c.uniform; out[5] = c.prefix; out[6] = c.redesc; out[7] = c.redesc_noop;
     return 0;
 }
 
@@ -1072,6 +1293,57 @@ extern "C" int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_l
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_per_launch = ms / iters;
+    return 0;
+}
+
+// ---- measurement support: what the last scoring pass's shared-prefix plan looks like ---------------------------------
+__global__ __launch_bounds__(256) void k_plan_stats(const pf::KdPlanRow *__restrict__ plan, size_t rows, const pf::KdGroupBox *__restrict__ box,
+                                                    int groups, double *__restrict__ out)
+{
+    double path = 0, cand = 0, done = 0, none = 0, full = 0, dx = 0, dy = 0, dt = 0;
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+        const pf::KdPlanRow *p = plan + r;
+        path += p->path_len;
+        cand += p->n_cand;
+        done += p->resume < 0;
+        none += p->path_len == 0;
+        full += p->n_cand == PF_PLAN_CAND;
+    }
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+        dx += box[g].xhi - box[g].xlo;
+        dy += box[g].yhi - box[g].ylo;
+        dt += box[g].thi - box[g].tlo;
+    }
+    double v[8] = {path, cand, done, none, full, dx, dy, dt};
+    for (int k = 0; k < 8; k++) {
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], v[k]);
+    }
+}
+// out[0] rows (waves x beams), [1] mean length of the common root path, [2] mean candidates kept of it, [3] fraction of rows whose
+// first descent is complete (no per-lane tail), [4] fraction without a plan (root straddled / unusable), [5] fraction with a full
+// candidate list, [6..8] mean extent of a wave's pose box in x, y (m) and heading (rad), [9] waves
+extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
+{
+    if (!h || !out) return fail("pfslam_plan_stats: bad argument");
+    for (int k = 0; k < 10; k++) out[k] = 0.0;
+    if (!h->plan || h->plan_rows == 0) return 0;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int groups = (h->n + 63) / 64;
+    const size_t rows = (size_t)groups * h->nb;
+    double *d = nullptr;
+    CHK(dalloc(&d, 8));
+    HIPCHK(hipMemsetAsync(d, 0, 64, h->stream));
+    hipLaunchKernelGGL(k_plan_stats, dim3(1024), dim3(256), 0, h->stream, (const pf::KdPlanRow *)h->plan, rows, (const pf::KdGroupBox *)h->group_box, groups, d);
+    HIPCHK(hipGetLastError());
+    double v[8];
+    HIPCHK(hipMemcpyAsync(v, d, 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d));
+    out[0] = (double)rows;
+    for (int k = 0; k < 5; k++) out[1 + k] = v[k] / (double)rows;
+    for (int k = 0; k < 3; k++) out[6 + k] = v[5 + k] / groups;
+    out[9] = groups;
     return 0;
 }
 

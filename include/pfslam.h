@@ -213,18 +213,24 @@ int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
  * pfslam_score_census: what one scoring launch on the handle's CURRENT particles, scan and map issues, counted by a counting
  *   instantiation of the same kernel with the same launch shape and lane order: out[0] wave-level trips of the descent loop
  *   (= wave-level 16-byte gathers of node records), out[1] active lanes in them (= node visits), out[2] wave-level
- *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them.
+ *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them, out[4] trips in which every
+ *   active lane stood on the same node, out[5] those of them on the common path of all 64 lanes from the root.
  * pfslam_set_variant: lane order of the scoring pass (results are bit-identical; A/B measurements): 0 = default (lanes along a
  *   Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys above), 6 = always the
  *   sorted 30-bit keys, 1 = identity order. */
 int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[12]);
-int pfslam_score_census(pfslam_handle *h, unsigned long long out[4]);
+int pfslam_score_census(pfslam_handle *h, unsigned long long out[8]);
 /* the chip's wave-level 16-byte gather rate measured live by a micro-benchmark (cache-resident 2 MB table, 8 waves per SIMD):
  * out[0] = wave gathers per second (whole chip), out[1] = compute units, out[2] = nominal clock in GHz, out[3] = cycles per
  * wave gather per CU at the nominal clock.  The scan-match kernel issues one such gather per node visit of a wave. */
 int pfslam_ubench_gather(pfslam_handle *h, double out[4]);
+/* the shared-prefix plan of the LAST scoring pass (kd_device.h): out[0] rows (waves x beams), [1] mean length of the root path
+ * common to a wave's 64 queries, [2] mean candidates kept of it, [3] fraction of rows whose first descent is complete,
+ * [4] fraction without a plan, [5] fraction with a full candidate list, [6..8] mean extent of a wave's pose box in x, y (m) and
+ * heading (rad), [9] waves.  All zero when no plan was made (non-planar map, few particles, variant 2). */
+int pfslam_plan_stats(pfslam_handle *h, double out[10]);
 int pfslam_set_variant(pfslam_handle *h, int variant);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */

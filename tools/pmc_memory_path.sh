@@ -21,7 +21,7 @@ import csv, glob, json, collections
 pm = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_score_kd" in r["Kernel_Name"]:
+        if "k_score_kd" in r["Kernel_Name"] and not __import__("re").search(r"true\s*>", r["Kernel_Name"]):
             pm[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in sorted(pm.items())}
 json.dump({"variant": $V, "kernel": "k_score_kd", "avg_per_launch": avg, "launches": {k: len(v) for k, v in pm.items()}}, open("gpurun_out/pmcmem_$TAG.json", "w"), indent=1)

@@ -22,6 +22,7 @@
 // constants of the reference (kernel.cu:30-52)
 // ------------------------------------------------------------------------------------------
 #define PF_LIDAR_RANGE 20.0f
+#define PF_RANGE_NEVER 28.4f /* > 20 * sqrt(2) with room for the 1-ulp sincos and the product's rounding */
 #define PF_FREE_WEIGHT (-1)
 #define PF_OCCUPIED_WEIGHT 4
 #define PF_EFFECTIVE_PARTICLES .7
@@ -288,8 +289,10 @@ __global__ __launch_bounds__(64) void k_plan(const pf::KdGroupBox *__restrict__ 
     int n_cand = 0, resume = 0, path_len = 0;
     float U = INFINITY; // upper bound (with margin) of the final minimum for every point of W
     // no plan (every lane walks from the root): non-finite or absurd geometry, NaN poses
+    // ... nor for a beam no lane can accept: |r| >= PF_RANGE_NEVER puts |r cos| or |r sin| beyond the 20 m reject of
+    // kernel.cu:1213 for every heading (max(|cos|, |sin|) >= 0.7071); the score kernel skips such beams outright
     const bool usable = (wxlo == wxlo) && (wxhi == wxhi) && (wylo == wylo) && (wyhi == wyhi) && fabsf(wxlo) < 1e6f && fabsf(wxhi) < 1e6f &&
-                        fabsf(wylo) < 1e6f && fabsf(wyhi) < 1e6f && (wxhi - wxlo) < 4.0f && (wyhi - wylo) < 4.0f;
+                        fabsf(wylo) < 1e6f && fabsf(wyhi) < 1e6f && (wxhi - wxlo) < 4.0f && (wyhi - wylo) < 4.0f && fabsf(r) < PF_RANGE_NEVER;
     if (usable) {
         int head = 0;
         while (head >= 0) {
@@ -383,6 +386,12 @@ __global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ 
     for (int j = j0; j < j1; j++) {
         const pf::KdPlanRow nxt = rows[min(j + 1, j1 - 1)]; // in flight while this beam is scored
         float wx, wy;
+        // wave-uniform: a beam of 28.4 m or more fails the +-20 m test below for every heading (20 * sqrt(2) = 28.28) -- and so
+        // does a NaN range; skipping it here saves the lanes the end-point arithmetic (synthetic scans clip at 30 m)
+        if (!(fabsf(cur.range) < PF_RANGE_NEVER)) {
+            cur = nxt;
+            continue;
+        }
         pf::clean_lidar_scan(j, cur.range, th, wx, wy);
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;

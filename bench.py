@@ -330,6 +330,8 @@ def main():
             out["cpu_baseline"] = cb
         launches = max(timers["score_launches"], 1)
         kern_s = max(timers["score_ms"] / launches, 1e-9) * 1e-3
+        plan_ms = timers["plan_ms"] / max(timers["plan_count"], 1)
+        plan_stats = e0.plan_stats()
         ub = e0.ubench_gather()
         # wave-level gathers per launch: mean of the census before and after the timed region.  A descent-loop trip is one
         # 16-byte wave gather; a parent-hyperplane test one 16-byte + one 4-byte wave gather.
@@ -356,11 +358,19 @@ def main():
         out["roofline"] = {
             "bound": "l1_gather", "achieved": achieved, "peak": peak_measured, "unit": "GB/s", "frac": achieved / peak_measured,
             "traffic": traffic,
-            "kernel": "k_score_kd", "kernel_ms": kern_s * 1e3, "launches": launches, "kernel_evals_per_s": n_local / kern_s,
+            "kernel": "k_score_kd_plan" if plan_stats["rows"] else "k_score_kd", "kernel_ms": kern_s * 1e3, "launches": launches,
+            "kernel_evals_per_s": n_local / kern_s,
+            "plan": dict(plan_stats, kernel_ms=plan_ms,
+                         note="shared-prefix plan of the LAST timed launch (pfslam_plan_stats): one planning lane per (wave, beam) walks "
+                              "the root path common to the wave's 64 queries and keeps only the nodes that can be nearest for some "
+                              "lane; kernel_ms = k_group_box + k_plan, which run before the scan-match kernel"),
             "definition": "achieved = lane-level bytes of the wave gathers one launch issues (16 B x 64 lanes per node-record gather, "
                           "4 B x 64 per parent-index gather; counted by pfslam_score_census before and after the timed region, mean) / "
                           "HIP-event time of the timed launches; peak = wave-gather rate of this chip measured in this process "
-                          "(pfslam_ubench_gather: cache-resident table, 8 waves/SIMD) x 1024 B",
+                          "(pfslam_ubench_gather: cache-resident table, 8 waves/SIMD) x 1024 B.  With the shared-prefix plan most node "
+                          "visits are evaluated from scalar registers and issue no gather at all, and the gathers that remain are the "
+                          "divergent ones (several cache lines each), so this fraction is a LOWER bound of the gather path's load: the "
+                          "PMC sub-block `ta_busy` has the counter",
             "gathers": {"wave_gathers_16B_per_launch": g16, "wave_gathers_4B_per_launch": g4, "lane_visits_per_launch": lane_visits,
                         "lanes_active_per_trip": lane_visits / max(0.5 * (census0["trips"] + census1["trips"]), 1.0),
                         "census_before": census0, "census_after": census1,
@@ -369,6 +379,12 @@ def main():
                            note="peak_nominal = CUs x 64 B/clk x nominal clock; the measured rate is what the same "
                                 "gather instruction sustains on this box"),
             "frac_of_nominal_peak": achieved / peak_nominal,
+            "ta_busy": None if not (pmc and pmc.get("avg_per_launch", {}).get("TA_TA_BUSY_sum") and pmc.get("avg_per_launch", {}).get("GRBM_GUI_ACTIVE")) else {
+                "frac": pmc["avg_per_launch"]["TA_TA_BUSY_sum"] / ub["cus"] / (pmc["avg_per_launch"]["GRBM_GUI_ACTIVE"] / 8.0),
+                "valu_insts_per_simd_cycle": (pmc["avg_per_launch"].get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (pmc["avg_per_launch"]["GRBM_GUI_ACTIVE"] / 8.0),
+                "source": os.path.relpath(pmc_path, ROOT),
+                "note": "TA_TA_BUSY_sum / CUs / (GRBM_GUI_ACTIVE / 8 XCDs): fraction of the kernel's cycles the texture addressers were "
+                        "busy; VALU wave-instructions per SIMD per cycle next to it (a wave64 VALU instruction occupies 2-4 cycles)"},
             "hbm": None if traffic is None else {
                 "bytes_per_launch": traffic, "achieved": traffic / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS, "source": os.path.relpath(pmc_path, ROOT),

@@ -240,7 +240,7 @@ class PfSlam:
         out = (C.c_double * 12)()
         _chk(self.L.pfslam_get_timers(self._h, out), "pfslam_get_timers")
         d = {"score_ms": out[0], "score_launches": int(out[1])}
-        for k, name in enumerate(("motion", "measurement", "map", "resample"), start=1):
+        for k, name in enumerate(("motion", "measurement", "map", "resample", "plan"), start=1):
             d[name + "_ms"] = out[2 * k]
             d[name + "_count"] = int(out[2 * k + 1])
         return d

@@ -31,7 +31,7 @@
 #define PF_SUM_TILE 4096
 #define PF_SCAN_TILE 1024
 #define PF_SCAN_CHUNK 16
-enum { PF_T_SCORE = 0, PF_T_MOTION, PF_T_MEASURE, PF_T_MAP, PF_T_RESAMPLE, PF_TIMER_SLOTS };
+enum { PF_T_SCORE = 0, PF_T_MOTION, PF_T_MEASURE, PF_T_MAP, PF_T_RESAMPLE, PF_T_PLAN, PF_TIMER_SLOTS };
 #define PF_KD_MAX_NODES ((1 << 27) - 1) /* idx << 4 must fit the 0x7ffffff0-byte buffer descriptor; links are 30-bit */
 
 extern "C" int pfslam_sort_pairs_u32(void *tmp, size_t *tmp_bytes, const unsigned *keys_in, unsigned *keys_out,
@@ -172,6 +172,7 @@ struct pfslam_handle {
     // shared-prefix plan of the score kernel: one row per (wave of 64 lanes, beam), pose box per wave
     pf::KdPlanRow *plan = nullptr;
     size_t plan_rows = 0;
+    bool plan_valid = false; // the last scoring pass made a plan
     pf::KdGroupBox *group_box = nullptr;
 };
 
@@ -933,7 +934,6 @@ extern "C" int pfslam_get_timers(pfslam_handle *h, double out[12])
         out[2 * k] = h->timer_ms[k];
         out[2 * k + 1] = (double)h->timer_count[k];
     }
-    out[10] = out[11] = 0.0;
     return 0;
 }
 
@@ -1188,10 +1188,13 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
     // (2.387 vs 2.400 ms with 256-thread groups)
     const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
-    // Shared-prefix plan (planar maps; variant 2 = off, the plain per-lane traversal, for A/B): pose box of every wave, then one
-    // planning lane per (wave, beam).  Below ~2 k particles the waves' boxes are too wide for the plan to pay for its launches.
-    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 2048;
-    const bool use_plan = h->planar && h->variant != 2 && h->n >= plan_min_n;
+    // Shared-prefix plan (planar maps; variant 2 = off, the plain per-lane traversal; variant 3 = on at any size; for A/B and
+    // tests): pose box of every wave, then one planning lane per (wave, beam).  With few particles the 64 poses of a wave lie
+    // too far apart for the plan to pay for its two launches: measured break-even ~6 k particles (scoring pass at 5 k / 10 k /
+    // 50 k particles: 0.203 / 0.313 / 0.841 ms with the plan, 0.198 / 0.353 / 1.327 ms without).
+    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 6144;
+    const bool use_plan = h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant == 3);
+    h->plan_valid = use_plan;
     if (use_plan) {
         const int groups = (h->n + 63) / 64;
         const size_t rows = (size_t)groups * h->nb;
@@ -1207,6 +1210,14 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box);
         hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                            (const float *)h->scan, h->nb, kd_view(h), h->plan);
+        if (t_a) { // the planning launches are timed on their own; t_a .. t_b brackets the scan-match kernel only
+            hipEvent_t t_p = nullptr;
+            CHK(timer_event(h, &t_p));
+            HIPCHK(hipEventRecord(t_p, h->stream));
+            h->ev_pending.push_back(pfslam_handle::TimedSpan{t_a, t_p, PF_T_PLAN});
+            CHK(timer_event(h, &t_a));
+            HIPCHK(hipEventRecord(t_a, h->stream));
+        }
         if (census)
             hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
                                kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, census);
@@ -1336,7 +1347,7 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
 {
     if (!h || !out) return fail("pfslam_plan_stats: bad argument");
     for (int k = 0; k < 10; k++) out[k] = 0.0;
-    if (!h->plan || h->plan_rows == 0) return 0;
+    if (!h->plan || !h->plan_valid) return 0;
     HIPCHK(hipSetDevice(h->cfg.device));
     const int groups = (h->n + 63) / 64;
     const size_t rows = (size_t)groups * h->nb;

@@ -209,15 +209,16 @@ int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
  *   kernel) inside pfslam_step / pfslam_shard_begin; 2 = additionally the four phases the reference times per frame
  *   (kernel.cu:1727-1760: motion, measurement incl. ICP, map update incl. its host part, resample).  Resets the accumulators.
  * pfslam_get_timers -> out[2k] = total ms, out[2k+1] = count, k = 0 scan-match kernel, 1 motion, 2 measurement, 3 map,
- *   4 resample; out[10..11] reserved (0).
+ *   4 resample, 5 the planning launches that precede the scan-match kernel (pose boxes + shared-prefix plan).
  * pfslam_score_census: what one scoring launch on the handle's CURRENT particles, scan and map issues, counted by a counting
  *   instantiation of the same kernel with the same launch shape and lane order: out[0] wave-level trips of the descent loop
  *   (= wave-level 16-byte gathers of node records), out[1] active lanes in them (= node visits), out[2] wave-level
  *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them, out[4] trips in which every
  *   active lane stood on the same node, out[5] those of them on the common path of all 64 lanes from the root.
- * pfslam_set_variant: lane order of the scoring pass (results are bit-identical; A/B measurements): 0 = default (lanes along a
- *   Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys above), 6 = always the
- *   sorted 30-bit keys, 1 = identity order. */
+ * pfslam_set_variant: how the scoring pass is organised (results are bit-identical; A/B measurements and tests): 0 = default
+ *   (lanes along a Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys above; the
+ *   shared-prefix plan from ~6 k particles), 6 = always the sorted 30-bit keys, 1 = identity lane order, 2 = no shared-prefix
+ *   plan (every lane walks the whole traversal), 3 = the plan at any particle count. */
 int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[12]);

@@ -228,3 +228,8 @@ def test_differential_fuzz_of_the_frame_loop():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_step.py"), "20", "7"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # and once more with the shared-prefix plan of the score kernel on at EVERY particle count (by default it starts at ~6 k
+    # particles): tiny waves, partly filled waves, NaN / Inf scans and clouds at the map edge all go through the planning kernel
+    env = dict(os.environ, PFSLAM_PLAN_MIN_N="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_step.py"), "15", "11"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

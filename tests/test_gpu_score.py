@@ -195,8 +195,13 @@ def test_lane_order_variants_are_bit_identical(gpu, small_world, variant):
         # no-op re-descents) and the census says how many
         assert 0 < c["visits"] <= visits and c["trips"] * 64 >= c["visits"] and c["tests"] * 64 >= c["test_lanes"] > 0
         assert c["redescents_noop"] <= c["redescents"]
-        h.set_variant(2)   # the plain per-lane traversal (no plan): same scores
-        assert (bits(h.score_kd()) == bits(want)).all()
+        for v in (2, 3):   # 2 = the plain per-lane traversal (no plan), 3 = the shared-prefix plan forced on: same scores
+            h.set_variant(v)
+            assert (bits(h.score_kd()) == bits(want)).all()
+            stats = h.plan_stats()
+            assert (stats["rows"] > 0) == (v == 3)
+            if v == 3:
+                assert stats["waves"] == (n + 63) // 64 and stats["candidates"] >= 1.0 and stats["path_len"] > 5
         h.set_variant(variant)
         assert (bits(h.score_kd()) == bits(want)).all()
         h.close()

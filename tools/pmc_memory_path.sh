@@ -14,14 +14,14 @@ for C in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_s
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
          "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -o pmc -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $C"
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -o pmc -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $C"
 done
 python - <<PY
 import csv, glob, json, collections
 pm = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_score_kd" in r["Kernel_Name"] and not __import__("re").search(r"true\s*>", r["Kernel_Name"]):
+        if "k_score_kd" in r["Kernel_Name"] and not __import__("re").search(r"(<|,\s*)true\s*>", r["Kernel_Name"]):
             pm[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in sorted(pm.items())}
 json.dump({"variant": $V, "kernel": "k_score_kd", "avg_per_launch": avg, "launches": {k: len(v) for k, v in pm.items()}}, open("gpurun_out/pmcmem_$TAG.json", "w"), indent=1)

@@ -11,11 +11,11 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT/summary
 CMD="python bench.py --no-cpu-baseline $ARGS"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/bench_kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/bench_kt.log 2>&1
 grep '^{' $OUT/bench_kt.log > $OUT/summary/bench_under_kernel_trace.json
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum"; do
   N=$(echo $C | cut -d' ' -f1)
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -o pmc -- $CMD > $OUT/bench_pmc_$N.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -o pmc -- $CMD > $OUT/bench_pmc_$N.log 2>&1
 done
 python - "$ARGS" <<PY
 import csv, glob, json, os, collections, sys, re
@@ -35,7 +35,7 @@ for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True):
 timed_ms = None
 for f in glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if "k_score_kd" in r["Kernel_Name"]]
-    plain = [r for r in rows if re.search(r"k_score_kd<\s*(true|false)\s*,\s*false\s*>", r["Kernel_Name"]) or not re.search(r",\s*true\s*>", r["Kernel_Name"])]
+    plain = [r for r in rows if not re.search(r"(<|,\s*)true\s*>", r["Kernel_Name"])]   # the counting instantiations end in <..., true>
     d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in plain)
     durs = [x[1] / 1e3 for x in d]
     timed = durs[workload["warmup"]:workload["warmup"] + workload["steps"]]
@@ -49,7 +49,7 @@ pm = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_score_kd" in k and not re.search(r",\s*true\s*>", k):
+        if "k_score_kd" in k and not re.search(r"(<|,\s*)true\s*>", k):
             pm[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in pm.items()}
 res = {"kernel": "k_score_kd", "workload": workload, "kernel_ms": timed_ms, "launches_profiled": {k: len(v) for k, v in pm.items()}, "avg_per_launch": avg}

@@ -13,7 +13,6 @@ INC = os.path.join("..", "..", "include", "pfslam.h")
 # source -> extra dependencies
 UNITS = {
     "pfslam_hip.hip": ["pf_math.h", "kd_device.h", "pfslam_stages.hip.inc", INC],
-    "sort_pairs.hip": [],
     "kd_host.cpp": [INC],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",

@@ -34,9 +34,6 @@
 enum { PF_T_SCORE = 0, PF_T_MOTION, PF_T_MEASURE, PF_T_MAP, PF_T_RESAMPLE, PF_T_PLAN, PF_TIMER_SLOTS };
 #define PF_KD_MAX_NODES ((1 << 27) - 1) /* idx << 4 must fit the 0x7ffffff0-byte buffer descriptor; links are 30-bit */
 
-extern "C" int pfslam_sort_pairs_u32(void *tmp, size_t *tmp_bytes, const unsigned *keys_in, unsigned *keys_out,
-                                     const int *vals_in, int *vals_out, int n, int end_bit, void *stream);
-
 static thread_local std::string g_err;
 static int fail(const std::string &m)
 {
@@ -99,11 +96,9 @@ struct pfslam_handle {
     float *fit = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
     // space-filling-curve processing order of the particles (performance only; results do not depend on it)
-    unsigned *mkey = nullptr, *mkey2 = nullptr;
-    int *order = nullptr, *order2 = nullptr;
+    unsigned *mkey = nullptr; // Hilbert cell of every particle
+    int *order2 = nullptr;    // lane -> particle
     int *cells = nullptr; // counting sort of the lane order: [2^18 cell counts | 2^18 cursors | 256 tile totals]
-    void *sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
     int64_t *stats = nullptr;
     float *pose = nullptr;  // device robotPos[4]
     float *start = nullptr; // device best-particle pose [4]
@@ -442,64 +437,23 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
     fit[order ? order[slot] : slot] = a;
 }
 
-// 30-bit space-filling-curve key of (heading, x, y) relative to the current robot pose: 1 mrad / 2 mm cells
-__device__ __forceinline__ unsigned spread10(unsigned v)
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-__global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ x, const float *__restrict__ y,
-                                                     const float *__restrict__ th, int n, const float *__restrict__ pose, float reach,
-                                                     unsigned *__restrict__ key, int *__restrict__ idx)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float qx = fminf(fmaxf((x[i] - pose[0]) * 500.0f + 512.0f, 0.0f), 1023.0f);
-    const float qy = fminf(fmaxf((y[i] - pose[1]) * 500.0f + 512.0f, 0.0f), 1023.0f);
-    const float qt = fminf(fmaxf((th[i] - pose[2]) * 500.0f * reach + 512.0f, 0.0f), 1023.0f); // 2 mm of end-point travel per cell
-    // Hilbert curve index (Skilling's axes-to-transpose, 10 bits x 3): unlike the plain bit interleave (Morton / Z-order) it has
-    // no long jumps, so 64 consecutive particles are always neighbours -- worth 1 % of the score kernel (2.38 vs 2.40 ms)
-    unsigned X[3] = {(unsigned)qt, (unsigned)qx, (unsigned)qy};
-    const unsigned M = 1u << 9;
-    for (unsigned Q = M; Q > 1; Q >>= 1) {
-        const unsigned P = Q - 1;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            if (X[a] & Q) X[0] ^= P;
-            else { const unsigned t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
-        }
-    }
-    X[1] ^= X[0]; X[2] ^= X[1];
-    unsigned t = 0;
-    for (unsigned Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
-    X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    key[i] = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
-    idx[i] = i;
-}
-
 // ------------------------------------------------------------------------------------------
-// Lane order in 3 launches instead of k_morton_keys + hipCUB's 10-launch merge sort: a counting sort over 2^18 Hilbert cells
-// laid over the particle cloud itself (64 cells per dimension across +-3.2 sigma around the mean, both estimated from the first
-// 1024 slots -- slots are exchangeable).  At 100 k particles the cells are as fine as the 2 mm / 1 mrad cells of the sorted
-// keys and almost every particle has a cell of its own, so the order inside a cell (atomic arrival order) does not matter.
+// Lane order in 3 launches: a counting sort over Hilbert cells laid over the particle cloud itself -- 2^18 cells (64 per
+// dimension) up to 400 k particles, 2^21 (128 per dimension) above -- across +-3.2 sigma around the mean, both estimated from
+// the first 1024 slots (slots are exchangeable).  There are more cells than particles, so almost every particle has a cell of
+// its own and the order inside a cell (atomic arrival order) does not matter.
 // The order only decides which lane scores which particle; results do not depend on it.
 //   k_cell_count:   cell of every particle (kept in `cell[]`), histogram with global atomics
-//   k_cell_scan:    exclusive scan inside 1024-cell tiles + tile totals (256 blocks); the counts are zeroed for the next frame
+//   k_cell_scan:    exclusive scan inside 1024-cell tiles + tile totals; the counts are zeroed for the next frame
 //   k_cell_scatter: slot = tile offset + atomicAdd(cursor[cell]) -> order[slot] = particle
 // ------------------------------------------------------------------------------------------
-#define PF_CELL_BITS 6
-#define PF_CELLS (1 << (3 * PF_CELL_BITS))
-__device__ __forceinline__ unsigned spread6(unsigned v) // 6 bits -> every third bit
+#define PF_CELL_BITS_MAX 7
+#define PF_CELLS_MAX (1 << (3 * PF_CELL_BITS_MAX))
+__device__ __forceinline__ unsigned spread3(unsigned v, int bits) // bit b of v -> bit 3 b
 {
-    v &= 0x3fu;
-    v = (v | (v << 8)) & 0x300fu;
-    v = (v | (v << 4)) & 0x30c3u;
-    v = (v | (v << 2)) & 0x9249u;
-    return v;
+    unsigned r = 0;
+    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1u) << (3 * b);
+    return r;
 }
 __device__ __forceinline__ float block_sum_256(float v, float *red)
 {
@@ -512,8 +466,8 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
 // reach: metres per radian -- a heading difference d moves a beam end point by ~ reach * d, so one cell is equally wide in x, y
 // and reach * theta (what makes the 64 queries of a wave a small box, see the shared-prefix plan)
 __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x, const float *__restrict__ y,
-                                                    const float *__restrict__ th, int n, float reach, unsigned *__restrict__ cell,
-                                                    int *__restrict__ hist)
+                                                    const float *__restrict__ th, int n, float reach, int bits,
+                                                    unsigned *__restrict__ cell, int *__restrict__ hist)
 {
     __shared__ float red[4];
     const int ns = min(n, 1024); // cloud statistics, identical in every block
@@ -526,18 +480,19 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
         const float a = x[k] - mx, b = y[k] - my, c = th[k] - mt;
         vx += a * a; vy += b * b; vt += c * c;
     }
-    // 64 cells over +-3.2 sigma of the widest dimension in the common metric (x, y, reach * theta): cell = 0.1 sigma of it,
-    // never finer than 0.25 mm
+    // D = 2^bits cells over +-3.2 sigma of the widest dimension in the common metric (x, y, reach * theta): cell = 6.4 sigma / D
+    // of it, never finer than 0.25 mm
     const float dev_x = sqrtf(block_sum_256(vx, red) * inv), dev_y = sqrtf(block_sum_256(vy, red) * inv);
     const float dev_t = sqrtf(block_sum_256(vt, red) * inv) * reach;
-    const float e = fmaxf(0.1f * fmaxf(fmaxf(dev_x, dev_y), dev_t), 2.5e-4f);
+    const float D = (float)(1 << bits), half = 0.5f * D, top = D - 1.0f;
+    const float e = fmaxf(6.4f / D * fmaxf(fmaxf(dev_x, dev_y), dev_t), 2.5e-4f);
     const float cx = 1.0f / e, cy = 1.0f / e, ct = reach / e;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    unsigned X[3] = {(unsigned)fminf(fmaxf((th[i] - mt) * ct + 32.0f, 0.0f), 63.0f),
-                     (unsigned)fminf(fmaxf((x[i] - mx) * cx + 32.0f, 0.0f), 63.0f),
-                     (unsigned)fminf(fmaxf((y[i] - my) * cy + 32.0f, 0.0f), 63.0f)};
-    const unsigned M = 1u << (PF_CELL_BITS - 1); // Hilbert index, Skilling's axes-to-transpose
+    unsigned X[3] = {(unsigned)fminf(fmaxf((th[i] - mt) * ct + half, 0.0f), top),
+                     (unsigned)fminf(fmaxf((x[i] - mx) * cx + half, 0.0f), top),
+                     (unsigned)fminf(fmaxf((y[i] - my) * cy + half, 0.0f), top)};
+    const unsigned M = 1u << (bits - 1); // Hilbert index, Skilling's axes-to-transpose
     for (unsigned Q = M; Q > 1; Q >>= 1) {
         const unsigned P = Q - 1;
 #pragma unroll
@@ -550,11 +505,11 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     unsigned t = 0;
     for (unsigned Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
     X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    const unsigned c = (spread6(X[0]) << 2) | (spread6(X[1]) << 1) | spread6(X[2]);
+    const unsigned c = (spread3(X[0], bits) << 2) | (spread3(X[1], bits) << 1) | spread3(X[2], bits);
     cell[i] = c;
     atomicAdd(&hist[c], 1);
 }
-// 256 blocks: exclusive scan inside every 1024-cell tile + the tile totals; the counts are zeroed for the next frame
+// one block per 1024-cell tile: exclusive scan inside the tile + the tile total; the counts are zeroed for the next frame
 __global__ __launch_bounds__(256) void k_cell_scan(int *__restrict__ hist, int *__restrict__ cursor, int *__restrict__ tile_tot)
 {
     __shared__ int wtot[4];
@@ -576,23 +531,28 @@ __global__ __launch_bounds__(256) void k_cell_scan(int *__restrict__ hist, int *
     if (threadIdx.x == 255) tile_tot[blockIdx.x] = base + s;
 }
 __global__ __launch_bounds__(256) void k_cell_scatter(const unsigned *__restrict__ cell, int n, int *__restrict__ cursor,
-                                                      const int *__restrict__ tile_tot, int *__restrict__ order)
+                                                      const int *__restrict__ tile_tot, int ntiles, int *__restrict__ order)
 {
-    // offsets of the 256 tiles: every block scans the tile totals itself (256 values)
-    __shared__ int tile_off[PF_CELLS / 1024];
+    // offsets of the tiles: every block scans the tile totals itself (256 or 2048 values, 256 at a time with a carry)
+    __shared__ int tile_off[PF_CELLS_MAX / 1024];
     __shared__ int wtot[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = tile_tot[threadIdx.x];
-    int inc = t;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += u;
+    int carry = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 256) {
+        const int t = tile_tot[t0 + threadIdx.x];
+        int inc = t;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        __syncthreads(); // wtot of the previous chunk has been read by everyone
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int base = carry + inc - t;
+        for (int k = 0; k < wave; k++) base += wtot[k];
+        tile_off[t0 + threadIdx.x] = base;
+        carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
     }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    int base = inc - t;
-    for (int k = 0; k < wave; k++) base += wtot[k];
-    tile_off[threadIdx.x] = base;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
@@ -716,12 +676,9 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
     CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
-    CHK(dalloc(&h->mkey, n)); CHK(dalloc(&h->mkey2, n)); CHK(dalloc(&h->order, n)); CHK(dalloc(&h->order2, n));
-    CHK(dalloc(&h->cells, (size_t)2 * PF_CELLS + PF_CELLS / 1024));
-    HIPCHK(hipMemsetAsync(h->cells, 0, ((size_t)2 * PF_CELLS + PF_CELLS / 1024) * sizeof(int), h->stream));
-    if (pfslam_sort_pairs_u32(nullptr, &h->sort_tmp_bytes, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, nullptr))
-        return fail("pfslam_create: radix sort workspace query failed");
-    HIPCHK(hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
+    CHK(dalloc(&h->mkey, n)); CHK(dalloc(&h->order2, n));
+    CHK(dalloc(&h->cells, (size_t)2 * PF_CELLS_MAX + PF_CELLS_MAX / 1024));
+    HIPCHK(hipMemsetAsync(h->cells, 0, ((size_t)2 * PF_CELLS_MAX + PF_CELLS_MAX / 1024) * sizeof(int), h->stream));
     CHK(dalloc(&h->stats, 8)); CHK(dalloc(&h->pose, 4)); CHK(dalloc(&h->start, 4));
     CHK(dalloc(&h->icp_tar, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_cor, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_dbg, 32));
     CHK(dalloc(&h->free_mask, 2 * M)); // the two masks are contiguous: one memset per frame
@@ -821,7 +778,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->pack, h->packs, h->scan, h->hot, h->parent, h->kz, h->kw,
-                    h->fit, h->fit_i, h->partial, h->mkey, h->mkey2, h->order, h->order2, h->cells, h->sort_tmp, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
+                    h->fit, h->fit_i, h->partial, h->mkey, h->order2, h->cells, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
                     h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->d_out, h->d_upd};
@@ -1159,25 +1116,17 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         out = h->partial;
     }
     const int *order = nullptr;
-    // default up to 400 k particles: counting sort over Hilbert cells of the cloud (3 launches; step 2.58 vs 2.61 ms at 100 k,
-    // 0.477 vs 0.496 ms at 10 k).  Beyond that several particles share a cell and the full sort's finer order wins
-    // (1 M particles: 22.55 vs 22.67 ms).
+    // default: counting sort over Hilbert cells of the cloud (3 launches), 2^18 cells up to 400 k particles, 2^21 above
     static const float theta_weight = getenv("PFSLAM_THETA_WEIGHT") ? (float)atof(getenv("PFSLAM_THETA_WEIGHT")) : 1.0f;
-    if (h->variant != 1 && h->variant != 6 && h->n > 64 && h->n <= 400000) {
-        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan_reach * theta_weight, h->mkey, h->cells);
-        hipLaunchKernelGGL(k_cell_scan, dim3(PF_CELLS / 1024), dim3(256), 0, h->stream, h->cells, h->cells + PF_CELLS, h->cells + 2 * PF_CELLS);
-        hipLaunchKernelGGL(k_cell_scatter, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->mkey, h->n, h->cells + PF_CELLS,
-                           h->cells + 2 * PF_CELLS, h->order2);
+    if (h->variant != 1 && h->n > 64) {
+        const int bits = h->n <= 400000 ? 6 : PF_CELL_BITS_MAX, ncell = 1 << (3 * bits);
+        int *hist = h->cells, *cursor = h->cells + ncell, *tile_tot = h->cells + 2 * ncell;
+        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan_reach * theta_weight, bits, h->mkey, hist);
+        hipLaunchKernelGGL(k_cell_scan, dim3(ncell / 1024), dim3(256), 0, h->stream, hist, cursor, tile_tot);
+        hipLaunchKernelGGL(k_cell_scatter, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->mkey, h->n, cursor, tile_tot, ncell / 1024, h->order2);
         HIPCHK(hipGetLastError());
         order = h->order2;
-    } else if (h->variant != 1 && h->n > 64) { // large N, or variant 6 (A/B): 30-bit Hilbert keys + radix sort; variant 1 = identity order
-        hipLaunchKernelGGL(k_morton_keys, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->pose, h->scan_reach * theta_weight,
-                           h->mkey, h->order);
-        size_t tb = h->sort_tmp_bytes;
-        if (pfslam_sort_pairs_u32(h->sort_tmp, &tb, h->mkey, h->mkey2, h->order, h->order2, h->n, 30, h->stream))
-            return fail("particle order sort failed");
-        order = h->order2;
-    }
+    } // variant 1 = identity lane order
     const int direct = used > 1 ? 0 : 1;
     hipEvent_t t_a = nullptr, t_b = nullptr;
     if (h->timing && !census) {

@@ -216,9 +216,9 @@ int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
  *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them, out[4] trips in which every
  *   active lane stood on the same node, out[5] those of them on the common path of all 64 lanes from the root.
  * pfslam_set_variant: how the scoring pass is organised (results are bit-identical; A/B measurements and tests): 0 = default
- *   (lanes along a Hilbert curve: counting sort over cells of the cloud up to 400 k particles, sorted 30-bit keys above; the
- *   shared-prefix plan from ~6 k particles), 6 = always the sorted 30-bit keys, 1 = identity lane order, 2 = no shared-prefix
- *   plan (every lane walks the whole traversal), 3 = the plan at any particle count. */
+ *   (lanes along a Hilbert curve: counting sort over cells of the cloud; the shared-prefix plan from ~6 k particles),
+ *   1 = identity lane order, 2 = no shared-prefix plan (every lane walks the whole traversal), 3 = the plan at any particle
+ *   count. */
 int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[12]);

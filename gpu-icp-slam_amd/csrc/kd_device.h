@@ -122,11 +122,17 @@ __device__ __forceinline__ void census_flush(const KdCensusLocal &c, KdCensus *o
 // kd_resume continues a traversal from the state (sBest, bestIdx, head) of its FIRST descent: the score kernel enters here
 // after it has worked off the part of the root path that the whole wave shares (see KdPlan below); head < 0 = the first
 // descent is already complete.  kd_nearest_ref is the whole traversal: resume from the root with nothing seen.
-template <bool PLANAR, bool CENSUS = false>
+//
+// LEAF: also report where the FIRST descent fell off the tree, as slot = node * 2 + (1 = right link, 0 = left link).  The
+// descent takes the left child exactly when query < node on the split axis, which is KDTree::InsertNode's rule
+// (kdtree.cpp:69-105), so that slot is where the query point would be inserted (the map update uses it, k_test_new).
+template <bool PLANAR, bool CENSUS = false, bool LEAF = false>
 __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, float pz, float sBest, int bestIdx, int head,
-                                         KdCensusLocal *census = nullptr)
+                                         KdCensusLocal *census = nullptr, int *leaf_slot = nullptr)
 {
     int prevBest = -1;
+    int leaf = -1;         // LEAF only
+    bool leaf_open = true; // LEAF only: still in the first descent
     const kd_rsrc_t hot_rsrc = kd_rsrc(t.hot), parent_rsrc = kd_rsrc(t.parent);
     bool on_prefix = head == 0; // census only: trips on the common path of all 64 lanes from the root
     bool in_redesc = false;     // census only
@@ -182,7 +188,12 @@ __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, fl
             const bool lt = da > 0.0f; // PLANAR z levels: both links hold the right child
             int left = hot_left(nd.z);
             if (!PLANAR) left = (t.planar && axis == 2) ? zleft : left;
+            if (LEAF && leaf_open) leaf = head * 2 + ((lt && !(PLANAR && axis == 2)) ? 0 : 1);
             head = lt ? left : (int)nd.w;
+        }
+        if (LEAF && leaf_open) {
+            leaf_open = false;
+            *leaf_slot = leaf;
         }
         // `nodeFullyExplored` of the reference == "the last re-descent did not change the best node"
         on_prefix = false;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <chrono>
@@ -56,13 +57,20 @@ static int fail(const std::string &m)
 // ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
-struct HostHeader { // packed by the device at the end of a step's kernel chain, read back in ONE D2H with the new walls
-    int32_t n_wall, n_free, n_new, pad0;
-    float r, r2, neff, pad1;
+// Everything the host needs from a frame: written by the device at the end of the frame's map-update chain straight into
+// pinned host memory (`seq` last, after a system-scope fence), read by the host one frame later -- or at once by any getter.
+struct HostHeader {
+    int32_t n_wall, n_free, n_new, kd_size;
+    float r, r2, neff;
+    int32_t flags; // PF_HDR_*
     float pose[4];
     int64_t stats[2];
+    int32_t seq; // ticket of the frame that wrote this slot
+    int32_t pad[15];
 };
-static_assert(sizeof(HostHeader) == 64, "HostHeader is 64 bytes, the new-wall list follows it");
+static_assert(sizeof(HostHeader) == 128, "HostHeader is two 64-byte lines");
+#define PF_HDR_SLOTS 4 /* header / scan staging slots: frames in flight + 1 (PF_MAX_LAG + 2) */
+#define PF_MAX_LAG 2
 
 struct pfslam_handle {
     pfslam_config cfg;
@@ -111,8 +119,9 @@ struct pfslam_handle {
     int *wall_cell = nullptr, *free_cell = nullptr;
     float4 *wall_pts = nullptr, *free_pts = nullptr;
     int *wall_c = nullptr, *free_c = nullptr;
-    float4 *new_pts = nullptr; // = d_out + sizeof(HostHeader)
-    int *counts = nullptr; // [0] n_wall [1] n_free [2] n_new
+    int *wall_leaf = nullptr; // link of the tree every wall point would be inserted on (node * 2 + right)
+    int *counts = nullptr;    // [0] n_wall [1] n_free [2] n_new [3] header flags of the last k_test_new
+    int *kd_state = nullptr;  // [0] map size, device side: the insert happens there (k_test_new)
     int max_free = 0, max_wall = 0;
     // resample scratch
     float *tile_r = nullptr, *tile_r2 = nullptr, *sums = nullptr; // sums: [r, r2, neff]
@@ -130,15 +139,15 @@ struct pfslam_handle {
     int *d_count = nullptr;
     int topo_in_step = 0;               // pfslam_set_topology: UpdateTopology + CheckLoopClosure at the end of every frame
     std::vector<int32_t> frame_closures; // (candidate node, visible node) pairs proposed by the last frame
-    // host mirrors / read-back
-    // device->host: [HostHeader | new walls (float4 x max_wall)], one copy per step into pinned memory
-    uint8_t *d_out = nullptr, *h_out = nullptr, *out_dev = nullptr; // out_dev: where the kernels write (d_out, or h_out's device view)
-    bool zero_copy = false;
-    size_t out_bytes = 0;
-    // host->device: packed tree updates of a step (new nodes + patched parents), one copy + one scatter kernel
-    uint8_t *d_upd = nullptr, *h_upd = nullptr;
-    size_t upd_bytes = 0;
-    float *h_scan = nullptr; // pinned staging of the scan
+    // Frame pipeline.  A frame's kernels need nothing from the host (the map insert and the resample decision are taken on
+    // the device), so pfslam_step only ENQUEUES frame t and then reads the header of frame t - lag: the host runs ahead of the
+    // device, there is no idle gap between frames.  Any other entry point settles the frames in flight first (settle()).
+    HostHeader *h_hdr = nullptr, *hdr_dev = nullptr; // PF_HDR_SLOTS pinned headers and their device view
+    float *h_scan = nullptr;                         // PF_HDR_SLOTS pinned scan staging buffers
+    struct Frame { int seq, frame, kind; };          // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once)
+    std::deque<Frame> in_flight;
+    int seq = 0; // tickets handed out
+    int lag = 1; // frames the host may run ahead (PFSLAM_LAG; 0 = every step settles itself)
     float scan_reach = 8.0f; // mean in-range beam length of the current scan (m): the lever arm of a heading difference
     std::vector<pfslam_particle> h_particles;
     std::vector<float> h_tmp;
@@ -147,8 +156,13 @@ struct pfslam_handle {
     // ICP needs only the scan, the previous pose and the map (kernel.cu:974-1075): it runs on `aux` under the score kernel
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_mapfork = nullptr, ev_map = nullptr; // map update of a frame on the aux stream (join_map)
+    bool map_forked = false;
     bool shard_map_done = false;  // pfslam_shard_map already launched this frame's map-update chain
     bool header_packed = false;   // k_test_new already filled the frame's HostHeader
+    bool lds_attr_set = false;    // k_test_new's dynamic LDS limit raised (scans of more than 1536 beams)
+    bool mirror_stale = false;    // the device has inserted nodes since h_nodes was last made current
+    int mirror_n = 0;             // nodes [0, mirror_n) of h_nodes are current except for links and weights (see pfslam_get_map)
     bool icp_forked = false;      // aux work in flight (between fork_icp and join_icp)
     bool icp_delta_ready = false; // joined: icp_dbg[24..27] holds this frame's increment, not yet added to the best particle
     bool masks_cleared = false;   // the aux stream already zeroed the free / wall masks for this frame
@@ -629,6 +643,8 @@ static int dalloc(T **p, size_t count)
 }
 
 static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw, h->planar}; }
+static int settle(pfslam_handle *h);   // finish and book the frames in flight (pfslam_stages.hip.inc)
+static int join_map(pfslam_handle *h); // main stream waits for the map update a frame left on the aux stream
 
 extern "C" int pfslam_destroy(pfslam_handle *h);
 
@@ -653,6 +669,8 @@ static int create_impl(pfslam_handle *h)
     HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_mapfork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming));
     const size_t n = h->n, M = (size_t)h->dimx * h->dimy, S = (size_t)h->stride;
     CHK(dalloc(&h->pblk, 3 * S)); CHK(dalloc(&h->pblk2, 3 * S)); CHK(dalloc(&h->w, S)); CHK(dalloc(&h->wm, S));
     HIPCHK(hipMemsetAsync(h->pblk, 0, 3 * S * 4, h->stream));
@@ -698,26 +716,19 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->src, n));
     CHK(dalloc(&h->grid, M));
     CHK(dalloc(&h->d_count, 4));
-    h->out_bytes = sizeof(HostHeader) + (size_t)h->max_wall * 16;
-    CHK(dalloc(&h->d_out, h->out_bytes));
-    HIPCHK(hipHostMalloc((void **)&h->h_out, h->out_bytes));
-    memset(h->h_out, 0, h->out_bytes);
-    // Zero-copy hand-over: the last kernels of a frame write the 64-byte header and the new walls straight into the pinned
-    // host buffer, and the patch kernel reads the packed node updates straight out of pinned host memory -- no D2H / H2D copy
-    // commands around the frame's host sync (PFSLAM_ZEROCOPY=0 restores the staged copies for A/B).
-    h->zero_copy = !(getenv("PFSLAM_ZEROCOPY") && atoi(getenv("PFSLAM_ZEROCOPY")) == 0);
-    if (h->zero_copy) {
+    CHK(dalloc(&h->wall_leaf, (size_t)h->max_wall));
+    CHK(dalloc(&h->kd_state, 4));
+    HIPCHK(hipMemsetAsync(h->kd_state, 0, 16, h->stream));
+    // headers and scan staging: pinned, coherent (the device writes a header while the stream keeps running, the host may poll it)
+    HIPCHK(hipHostMalloc((void **)&h->h_hdr, PF_HDR_SLOTS * sizeof(HostHeader), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h->h_hdr, 0, PF_HDR_SLOTS * sizeof(HostHeader));
+    {
         void *dp = nullptr;
-        HIPCHK(hipHostGetDevicePointer(&dp, h->h_out, 0));
-        h->out_dev = (uint8_t *)dp;
-    } else {
-        h->out_dev = h->d_out;
+        HIPCHK(hipHostGetDevicePointer(&dp, h->h_hdr, 0));
+        h->hdr_dev = (HostHeader *)dp;
     }
-    h->new_pts = (float4 *)(h->out_dev + sizeof(HostHeader));
-    h->upd_bytes = 64 + (size_t)((h->max_wall + 3) & ~3) * (16 + 4 + 4 + 4 + 4 + 16 + 4);
-    CHK(dalloc(&h->d_upd, h->upd_bytes));
-    HIPCHK(hipHostMalloc((void **)&h->h_upd, h->upd_bytes));
-    HIPCHK(hipHostMalloc((void **)&h->h_scan, (size_t)h->nb * 4));
+    HIPCHK(hipHostMalloc((void **)&h->h_scan, (size_t)PF_HDR_SLOTS * h->nb * 4));
+    if (const char *e = getenv("PFSLAM_LAG")) h->lag = std::min(std::max(atoi(e), 0), PF_MAX_LAG);
     h->h_nodes.reserve(1024);
     // particleFilterInit (kernel.cu:122-132): grid = -100, particles at the origin with w = 1, robotPos = 0
     std::vector<float> ones(n, 1.0f);
@@ -740,6 +751,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     if (cfg->n_particles <= 0 || cfg->n_beams <= 0 || cfg->kd_capacity <= 0)
         return fail("pfslam_create: n_particles, n_beams and kd_capacity must be positive");
     if (cfg->n_particles > (1 << 24)) return fail("pfslam_create: at most 2^24 particles per handle");
+    if (cfg->n_beams > 4096) return fail("pfslam_create: at most 4096 beams per scan (the map insert keeps a frame's new walls in LDS)");
     if (cfg->kd_capacity > PF_KD_MAX_NODES) return fail("pfslam_create: kd_capacity above 2^27 - 1 nodes (32-bit byte offsets of the map records)");
     if (!(cfg->map_res_x > 0.0f && cfg->map_res_y > 0.0f && cfg->map_scale_x > 0.0f && cfg->map_scale_y > 0.0f))
         return fail("pfslam_create: map scale and resolution must be positive");
@@ -781,20 +793,21 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
                     h->fit, h->fit_i, h->partial, h->mkey, h->order2, h->cells, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
-                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->d_out, h->d_upd};
+                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->wall_leaf, h->kd_state};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_global) {
         (void)hipFree(h->gw); (void)hipFree(h->gpose);
     }
-    if (h->h_out) (void)hipHostFree(h->h_out);
-    if (h->h_upd) (void)hipHostFree(h->h_upd);
+    if (h->h_hdr) (void)hipHostFree(h->h_hdr);
     if (h->h_scan) (void)hipHostFree(h->h_scan);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_mapfork) (void)hipEventDestroy(h->ev_mapfork);
+    if (h->ev_map) (void)hipEventDestroy(h->ev_map);
     for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->phase_ev) (void)hipEventDestroy(h->phase_ev);
@@ -809,6 +822,8 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
 extern "C" int pfslam_set_stream(pfslam_handle *h, void *hip_stream)
 {
     if (!h) return fail("null handle");
+    CHK(settle(h));
+    if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) {
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipStreamDestroy(h->stream));
@@ -821,6 +836,7 @@ extern "C" int pfslam_set_stream(pfslam_handle *h, void *hip_stream)
 extern "C" int pfslam_synchronize(pfslam_handle *h)
 {
     if (!h) return fail("null handle");
+    CHK(settle(h)); // books the frames in flight: a deferred error of one of them is reported here
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -909,6 +925,10 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     if (n == 0) {
         h->h_nodes.clear();
         h->kd_size = 0;
+        h->mirror_n = 0;
+        h->mirror_stale = false;
+        HIPCHK(hipMemsetAsync(h->kd_state, 0, 16, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
         return 0;
     }
     std::vector<uint4> hot(n);
@@ -937,9 +957,13 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kw, w.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    const int state[4] = {n, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->kd_state, state, 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->h_nodes.assign(nodes, nodes + n);
     h->kd_size = n;
+    h->mirror_n = n;
+    h->mirror_stale = false;
     h->planar = planar;
     h->integral_w = integral;
     return 0;
@@ -949,6 +973,7 @@ extern "C" int pfslam_set_map(pfslam_handle *h, const pfslam_node *nodes, int n)
 {
     if (!h || (n > 0 && !nodes) || n < 0) return fail("pfslam_set_map: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     return upload_tree(h, nodes, n);
 }
 
@@ -956,6 +981,7 @@ extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, 
 {
     if (!h || !p || n != h->n) return fail("pfslam_set_particles: n must equal cfg.n_particles");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     std::vector<float> tmp(4 * (size_t)n);
     for (int i = 0; i < n; i++) {
         tmp[i] = p[i].x; tmp[n + i] = p[i].y; tmp[2 * (size_t)n + i] = p[i].theta; tmp[3 * (size_t)n + i] = p[i].w;
@@ -988,6 +1014,7 @@ extern "C" int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_b
 {
     if (!h || !scan_host || n_beams != h->nb) return fail("pfslam_set_scan: n_beams must equal cfg.n_beams");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     scan_reach_of(h, scan_host);
     HIPCHK(hipMemcpyAsync(h->scan, scan_host, (size_t)n_beams * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream)); // scan_host is pageable: do not return before it is consumed
@@ -997,6 +1024,7 @@ extern "C" int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_b
 extern "C" int pfslam_set_pose(pfslam_handle *h, const float pose[3])
 {
     if (!h || !pose) return fail("pfslam_set_pose: bad argument");
+    CHK(settle(h));
     float p4[4] = {pose[0], pose[1], pose[2], 0.0f};
     memcpy(h->h_pose, pose, 12);
     HIPCHK(hipMemcpyAsync(h->pose, p4, 16, hipMemcpyHostToDevice, h->stream));
@@ -1008,6 +1036,7 @@ extern "C" int pfslam_get_particles(pfslam_handle *h, const pfslam_particle **ou
 {
     if (!h || !out || !n) return fail("pfslam_get_particles: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     const size_t N = h->n;
     h->h_tmp.resize(4 * N);
     HIPCHK(hipMemcpyAsync(&h->h_tmp[0], h->x, N * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1030,11 +1059,47 @@ extern "C" int pfslam_get_map(pfslam_handle *h, const pfslam_node **out, int *n)
 {
     if (!h || !out || !n) return fail("pfslam_get_map: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     const size_t K = h->kd_size;
-    if (K) { // topology and positions live in the host mirror; only the weights change on the device
+    if (K) {
+        // The device owns the tree: weights change every frame and the map update inserts there.  The host mirror keeps what
+        // never changes (position, axis, parent of the nodes it has seen); links and weights are read back, and so are the nodes
+        // appended since the last call.  (A planar z-level node never gains a LEFT child, so its mirrored left link stays valid.)
+        const size_t M0 = std::min((size_t)h->mirror_n, K);
+        std::vector<uint4> hot(K);
         h->h_tmp.resize(K);
+        std::vector<int> par(K - M0);
+        std::vector<float> z(K - M0);
         HIPCHK(hipMemcpyAsync(h->h_tmp.data(), h->kw, K * 4, hipMemcpyDeviceToHost, h->stream));
+        if (h->mirror_stale) {
+            HIPCHK(hipMemcpyAsync(hot.data(), h->hot, K * 16, hipMemcpyDeviceToHost, h->stream));
+            if (K > M0) {
+                HIPCHK(hipMemcpyAsync(par.data(), h->parent + M0, (K - M0) * 4, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(z.data(), h->kz + M0, (K - M0) * 4, hipMemcpyDeviceToHost, h->stream));
+            }
+        }
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->mirror_stale) {
+            h->h_nodes.resize(K);
+            const bool planar = h->planar != 0;
+            for (size_t i = 0; i < K; i++) {
+                pfslam_node &nd = h->h_nodes[i];
+                const int axis = (int)(hot[i].z >> 30);
+                if (i >= M0) {
+                    memcpy(&nd.x, &hot[i].x, 4);
+                    memcpy(&nd.y, &hot[i].y, 4);
+                    nd.axis = axis;
+                    nd.parent = par[i - M0];
+                    nd.z = planar ? 0.0f : z[i - M0];
+                    nd.left = -1;
+                    if (planar && axis == 2) memcpy(&nd.left, &z[i - M0], 4);
+                }
+                if (!(planar && axis == 2)) nd.left = pf::hot_left(hot[i].z);
+                nd.right = (int)hot[i].w;
+            }
+            h->mirror_n = (int)K;
+            h->mirror_stale = false;
+        }
         for (size_t i = 0; i < K; i++) h->h_nodes[i].w = h->h_tmp[i];
     }
     *out = h->h_nodes.data();
@@ -1045,6 +1110,7 @@ extern "C" int pfslam_get_map(pfslam_handle *h, const pfslam_node **out, int *n)
 extern "C" int pfslam_get_pose(pfslam_handle *h, float pose[3])
 {
     if (!h || !pose) return fail("pfslam_get_pose: bad argument");
+    CHK(settle(h));
     float p4[4];
     HIPCHK(hipMemcpyAsync(p4, h->pose, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1056,6 +1122,7 @@ extern "C" int pfslam_get_pose(pfslam_handle *h, float pose[3])
 extern "C" int pfslam_get_trace(pfslam_handle *h, int32_t out[8])
 {
     if (!h || !out) return fail("pfslam_get_trace: bad argument");
+    CHK(settle(h)); // the trace of the LAST frame: every frame in flight is booked first
     memcpy(out, h->trace, sizeof(h->trace));
     return 0;
 }
@@ -1065,6 +1132,7 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
 {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     hipLaunchKernelGGL(k_motion, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->w, h->wm,
                        h->n, frame, h->goff);
     HIPCHK(hipGetLastError());
@@ -1128,6 +1196,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         order = h->order2;
     } // variant 1 = identity lane order
     const int direct = used > 1 ? 0 : 1;
+    CHK(join_map(h)); // from here on the scoring pass reads the map (the lane order above did not)
     hipEvent_t t_a = nullptr, t_b = nullptr;
     if (h->timing && !census) {
         CHK(timer_event(h, &t_a));
@@ -1228,6 +1297,7 @@ extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[8])
 {
     if (!h || !out) return fail("pfslam_score_census: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     if (!h->d_census) CHK(dalloc(&h->d_census, 1));
     HIPCHK(hipMemsetAsync(h->d_census, 0, sizeof(pf::KdCensus), h->stream));
     CHK(launch_score(h, false, h->d_census));
@@ -1242,6 +1312,7 @@ extern "C" int pfslam_score_kd(pfslam_handle *h, float *fit_host)
 {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     CHK(launch_score(h));
     if (fit_host) {
         HIPCHK(hipMemcpyAsync(fit_host, h->fit, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1254,6 +1325,7 @@ extern "C" int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_l
 {
     if (!h || iters <= 0 || !ms_per_launch) return fail("pfslam_time_score_kd: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     CHK(launch_score(h)); // warm
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int k = 0; k < iters; k++) CHK(launch_score(h));
@@ -1298,6 +1370,7 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
     for (int k = 0; k < 10; k++) out[k] = 0.0;
     if (!h->plan || !h->plan_valid) return 0;
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     const int groups = (h->n + 63) / 64;
     const size_t rows = (size_t)groups * h->nb;
     double *d = nullptr;
@@ -1346,6 +1419,7 @@ extern "C" int pfslam_ubench_gather(pfslam_handle *h, double out[4])
 {
     if (!h || !out) return fail("pfslam_ubench_gather: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
     const int cus = prop.multiProcessorCount, n_rec = 131072, iters = 400;
@@ -1385,6 +1459,7 @@ extern "C" int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, i
     if (h->kd_size <= 0) return fail("pfslam_traverse: no map loaded");
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     float *d_xyz = nullptr;
     int *d_best = nullptr;
     CHK(dalloc(&d_xyz, (size_t)n * 3));
@@ -1410,6 +1485,7 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
 {
     if (!h || !in_host || !out_host || n <= 0) return fail("pfslam_debug_math: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
     const int per = which == 0 ? 2 : 1;
     float *d_in = nullptr, *d_out = nullptr;
     CHK(dalloc(&d_in, (size_t)n));
@@ -1427,6 +1503,7 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
 extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes)
 {
     if (!h || !ptr || !bytes) return fail("pfslam_device_ptr: bad argument");
+    CHK(settle(h));
     const size_t n = h->n;
     switch (which) {
     case 0: *ptr = h->stats; *bytes = 64; break;

@@ -65,6 +65,7 @@ while time.time() < t_end:
                 o.step_grid(f, scan); h.step_grid(f, scan)
             else:
                 o.step(f, scan); h.step(f, scan)
+            h.synchronize()  # pfslam_step only enqueues the frame: a deferred error is reported by the call that books it
         except pkg.PfSlamError as e:
             # the only legitimate refusal: map capacity exhausted -- the product fails loudly where the oracle (like the
             # reference, which has no bound check at all) just stops inserting; the case ends there

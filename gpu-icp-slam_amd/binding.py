@@ -22,7 +22,7 @@ SYMBOLS = [
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
-    "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant",
+    "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
     "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_ubench_gather", "pfslam_plan_stats",
 ]
@@ -133,6 +133,7 @@ def load():
     L.pfslam_device_ptr.argtypes = [vp, i32, vp, vp]
     L.pfslam_time_score_kd.argtypes = [vp, i32, vp]
     L.pfslam_set_variant.argtypes = [vp, i32]
+    L.pfslam_set_lag.argtypes = [vp, i32]
     L.pfslam_kd_create.argtypes = [vp, i32, vp]
     L.pfslam_kd_insert_node.argtypes = [vp, vp, i32]
     L.pfslam_kd_insert_list.argtypes = [vp, i32, vp, i32, i32]
@@ -244,6 +245,10 @@ class PfSlam:
             d[name + "_ms"] = out[2 * k]
             d[name + "_count"] = int(out[2 * k + 1])
         return d
+
+    def set_lag(self, frames):
+        """Frames pfslam_step may leave in flight (0 = every step books its own frame before it returns; default 1)."""
+        _chk(self.L.pfslam_set_lag(self._h, frames), "pfslam_set_lag")
 
     def synchronize(self):
         _chk(self.L.pfslam_synchronize(self._h), "pfslam_synchronize")

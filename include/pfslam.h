@@ -62,8 +62,9 @@ typedef struct pfslam_config {
     float map_res_x, map_res_y;     /* Patch.resolution (0.025).  int(scale / res) must be the same in x and y: the
                                      * reference indexes cell (x, y) as x * dim.x + y (kernel.cu:120, 539, 1438), which is
                                      * only well defined on a square grid; pfslam_create refuses anything else */
-    int32_t kd_capacity;   /* KD_MAX_SIZE (kernel.cu:77); nodes, at most 2^27 - 1.  A frame whose new walls do not fit makes
-                            * pfslam_step fail ("kd_capacity exhausted") -- the reference has no bound check at all */
+    int32_t kd_capacity;   /* KD_MAX_SIZE (kernel.cu:77); nodes, at most 2^27 - 1.  A frame whose new walls do not fit inserts
+                            * none of them and fails ("kd_capacity exhausted"; reported by the call that books the frame, see
+                            * pfslam_step) -- the reference has no bound check at all */
     int32_t device;        /* HIP device ordinal */
     int32_t strict_host_mirror; /* 1 = reproduce the half-array weight read-back of kernel.cu:1341 (H11) */
     int32_t free_upload_bug;    /* 1 = reproduce kernel.cu:1475 (free list tail zero) (H6); 0 = full list */
@@ -92,10 +93,21 @@ const char *pfslam_last_error(void);
 int pfslam_device_count(void);
 /* launch on this HIP stream (hipStream_t as void*) instead of the handle's own */
 int pfslam_set_stream(pfslam_handle *h, void *hip_stream);
+/* books every frame in flight (see pfslam_step), then waits for the stream */
 int pfslam_synchronize(pfslam_handle *h);
 
-/* ---- whole step (kernel.h:16) ---- */
+/* ---- whole step (kernel.h:16) ----
+ * pfslam_step ENQUEUES the frame -- dispersion, scan-match, weights, ICP, map update including the insert of the new walls
+ * (KDTree::InsertNode on the device), resample decided on the device -- copies the scan into a pinned slot of its own, and
+ * then books the frame `lag` steps back (default 1): trace, pose, map size and deferred errors come from a 128-byte header the
+ * device writes into pinned memory.  Successive calls therefore overlap the host with the device and leave no idle gap between
+ * frames.  EVERY other entry point first books all frames in flight, so pfslam_step followed by any getter behaves like the
+ * reference's synchronous particleFilter.  A deferred error (kd_capacity exhausted, cell list overflow) is returned by the call
+ * that books the frame: the next pfslam_step, a getter, or pfslam_synchronize.  The first scan (it seeds the map on the host),
+ * re-balance frames and handles with pfslam_set_topology(h, 1) are booked at once.
+ * pfslam_set_lag: 0 = every pfslam_step books its own frame before it returns, up to 2 frames in flight. */
 int pfslam_step(pfslam_handle *h, int frame, const float *scan_host);
+int pfslam_set_lag(pfslam_handle *h, int frames);
 /* The same frame loop with the reference's 2-D occupancy-grid stages (PFMotionUpdate kernel.cu:400-418,
  * PFMeasurementUpdate 307-339, PFUpdateMap 551-577, PFResample 447-511): pose = best particle, grid updated
  * in place.  The grid starts at -100 everywhere (kernel.cu:124) unless pfslam_set_grid replaced it. */

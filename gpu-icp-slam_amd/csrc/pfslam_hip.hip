@@ -171,7 +171,7 @@ struct pfslam_handle {
     // timing == 1: HIP events bracket every k_score_kd launch (bench.py roofline leg).  timing == 2: also the four phases the
     // reference times per frame (kernel.cu:1727-1760): motion / measurement / map / resample.
     int timing = 0;
-    struct TimedSpan { hipEvent_t a, b; int slot; };
+    struct TimedSpan { hipEvent_t a, b; int slot; bool keep_b = false; }; // keep_b: b is also the start of the next span
     std::vector<hipEvent_t> ev_pool;
     std::vector<TimedSpan> ev_pending;
     hipEvent_t phase_ev = nullptr; // start of the phase being timed
@@ -788,6 +788,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
 {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
+    (void)settle(h); // frames in flight finish first (their deferred errors are the caller's to collect: pfslam_synchronize)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->pack, h->packs, h->scan, h->hot, h->parent, h->kz, h->kw,
                     h->fit, h->fit_i, h->partial, h->mkey, h->order2, h->cells, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
@@ -809,7 +810,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->ev_mapfork) (void)hipEventDestroy(h->ev_mapfork);
     if (h->ev_map) (void)hipEventDestroy(h->ev_map);
     for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
-    for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); if (!e.keep_b) (void)hipEventDestroy(e.b); }
     if (h->phase_ev) (void)hipEventDestroy(h->phase_ev);
     if (h->d_census) (void)hipFree(h->d_census);
     if (h->plan) (void)hipFree(h->plan);
@@ -851,7 +852,7 @@ static int flush_timers(pfslam_handle *h)
         h->timer_ms[e.slot] += ms;
         h->timer_count[e.slot] += 1;
         h->ev_pool.push_back(e.a);
-        h->ev_pool.push_back(e.b);
+        if (!e.keep_b) h->ev_pool.push_back(e.b);
     }
     h->ev_pending.clear();
     return 0;
@@ -1228,13 +1229,12 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box);
         hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                            (const float *)h->scan, h->nb, kd_view(h), h->plan);
-        if (t_a) { // the planning launches are timed on their own; t_a .. t_b brackets the scan-match kernel only
+        if (t_a) { // the planning launches are timed on their own: t_a .. t_p; t_p .. t_b brackets the scan-match kernel only
             hipEvent_t t_p = nullptr;
             CHK(timer_event(h, &t_p));
             HIPCHK(hipEventRecord(t_p, h->stream));
-            h->ev_pending.push_back(pfslam_handle::TimedSpan{t_a, t_p, PF_T_PLAN});
-            CHK(timer_event(h, &t_a));
-            HIPCHK(hipEventRecord(t_a, h->stream));
+            h->ev_pending.push_back(pfslam_handle::TimedSpan{t_a, t_p, PF_T_PLAN, /*keep_b=*/true});
+            t_a = t_p;
         }
         if (census)
             hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,

@@ -198,7 +198,10 @@ void particleFilterInit(Scene *scene)
 }
 void particleFilterFree()
 {
-    if (g_handle) PFCHK(pfslam_destroy(g_handle), "particleFilterFree");
+    if (g_handle) {
+        PFCHK(pfslam_synchronize(g_handle), "particleFilterFree (a frame still in flight failed)"); // deferred errors of the last frame
+        PFCHK(pfslam_destroy(g_handle), "particleFilterFree");
+    }
     g_handle = nullptr;
     particleFilterFreePC();
 }

@@ -192,7 +192,8 @@ int pfslam_kd_size(pfslam_handle *h);
  *                           best particle + increment of the ICP solve (which ran under the score kernel)
  *   [all-gather buffer 5 -> buffer 10]                         weights, shard_stride floats per rank; may overlap with ...
  *   pfslam_shard_map        ... the replicated map update's device chain (optional call; shard_finish runs it otherwise)
- *   pfslam_shard_finish     Neff on the gathered weights, host sync, host insert; resample plan when Neff < 0.7 N
+ *   pfslam_shard_finish     Neff on the gathered weights, frame header, the one host wait; resample plan when Neff < 0.7 N
+ *                           (the new walls were inserted on the device by pfslam_shard_map)
  *   [all-gather buffer 16 -> buffer 17]  pfslam_resample_gather   only when *resampled: [x | y | theta] in ONE piece of
  *                                                                3 * shard_stride floats per rank
  * i.e. two collectives per frame, three in frames that resample.  Results are bit-identical for any number of ranks. */

@@ -92,7 +92,8 @@ struct pfslam_handle {
     // sharded measurement merge: this rank's {max key, negated-min key, pose of its best particle} (32 bytes) and the
     // all-gathered records of every rank
     long long *pack = nullptr, *packs = nullptr;
-    float *scan = nullptr;
+    float *scan = nullptr;      // the current frame's scan on the device: one of the PF_HDR_SLOTS slots of scan_base
+    float *scan_base = nullptr; // (the map update of frame t may still read its scan while frame t + 1's is uploaded)
     // map
     int kd_size = 0, kd_cap = 0, planar = 1;
     uint4 *hot = nullptr;
@@ -690,7 +691,8 @@ static int create_impl(pfslam_handle *h)
         h->gw = h->w;
         h->gpose = h->pblk;
     }
-    CHK(dalloc(&h->scan, (size_t)h->nb));
+    CHK(dalloc(&h->scan_base, (size_t)h->nb * PF_HDR_SLOTS));
+    h->scan = h->scan_base;
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
     CHK(dalloc(&h->fit, n)); CHK(dalloc(&h->fit_i, n));
@@ -790,7 +792,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)settle(h); // frames in flight finish first (their deferred errors are the caller's to collect: pfslam_synchronize)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->pack, h->packs, h->scan, h->hot, h->parent, h->kz, h->kw,
+    void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->pack, h->packs, h->scan_base, h->hot, h->parent, h->kz, h->kw,
                     h->fit, h->fit_i, h->partial, h->mkey, h->order2, h->cells, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,

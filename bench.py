@@ -421,8 +421,9 @@ def main():
             if out is not None:
                 out["phases_ms"] = {name: t[name + "_ms"] / max(t[name + "_count"], 1) for name in ("motion", "measurement", "map", "resample")}
                 out["phases_ms"]["note"] = ("HIP events on the step's stream, mean of 20 frames: motion = dispersion; measurement = lane "
-                                            "order + scan-match + reduce/min/max + weights + Neff (ICP runs under it); map = device chain + "
-                                            "host insert and its sync; resample = averaged over all frames (most do not resample)")
+                                            "order + scan-match + reduce/min/max + weights + Neff (ICP runs under it); map = device chain incl. the "
+                                            "insert of the new walls, kept on the main stream while the phases are timed (it runs on the aux "
+                                            "stream otherwise); resample = the five gated launches, averaged over all frames")
     if out is not None:
         if world == 1 and not a.no_cpu_baseline:
             import oracle_lib as O

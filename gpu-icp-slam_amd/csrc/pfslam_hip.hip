@@ -1162,6 +1162,7 @@ struct ShardPack;
 __global__ void k_reduce_partials_minmax(const float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
                                          const float *x, const float *y, const float *th, ShardPack *pack);
 __global__ void k_shard_pack(const long long *stats, const float *x, const float *y, const float *th, int n, int goff, ShardPack *pack);
+__global__ void k_reduce_partials_minmax_wide(const float *partial, int n, int chunks, const int *order, float *fit, long long *stats);
 template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
 static int join_icp(pfslam_handle *h);
 static int launch_stats_reset(pfslam_handle *h, hipStream_t st);
@@ -1266,7 +1267,11 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (!h->stats_clean) CHK(launch_stats_reset(h, h->stream));
         h->stats_clean = false;
     }
-    if (used > 1 && fuse_minmax) {
+    if (used >= 256 && fuse_minmax && !shard_pack && h->goff == 0) { // few particles, one beam per wave: 16 threads per particle
+        hipLaunchKernelGGL(k_reduce_partials_minmax_wide, dim3((h->n + 63) / 64), dim3(1024), 0, h->stream, h->partial, h->n, used, order,
+                           h->fit, (long long *)h->stats);
+        HIPCHK(hipGetLastError());
+    } else if (used > 1 && fuse_minmax) {
         hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n, used, order,
                            h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th, shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr);
         HIPCHK(hipGetLastError());

@@ -159,6 +159,7 @@ struct pfslam_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_mapfork = nullptr, ev_map = nullptr; // map update of a frame on the aux stream (join_map)
     bool map_forked = false;
+    bool scan_front_done = false; // tile totals and offsets of the resample scan were produced with the weight sums of this frame
     bool shard_map_done = false;  // pfslam_shard_map already launched this frame's map-update chain
     bool header_packed = false;   // k_test_new already filled the frame's HostHeader
     bool lds_attr_set = false;    // k_test_new's dynamic LDS limit raised (scans of more than 1536 beams)

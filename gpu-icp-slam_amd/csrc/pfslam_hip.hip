@@ -1201,16 +1201,6 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         order = h->order2;
     } // variant 1 = identity lane order
     const int direct = used > 1 ? 0 : 1;
-    CHK(join_map(h)); // from here on the scoring pass reads the map (the lane order above did not)
-    hipEvent_t t_a = nullptr, t_b = nullptr;
-    if (h->timing && !census) {
-        CHK(timer_event(h, &t_a));
-        CHK(timer_event(h, &t_b));
-        HIPCHK(hipEventRecord(t_a, h->stream));
-    }
-    // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
-    // (2.387 vs 2.400 ms with 256-thread groups)
-    const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
     // Shared-prefix plan (planar maps; variant 2 = off, the plain per-lane traversal; variant 3 = on at any size; for A/B and
     // tests): pose box of every wave, then one planning lane per (wave, beam).  With few particles the 64 poses of a wave lie
     // too far apart for the plan to pay for its two launches: measured break-even ~6 k particles (scoring pass at 5 k / 10 k /
@@ -1218,7 +1208,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 6144;
     const bool use_plan = h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant == 3);
     h->plan_valid = use_plan;
-    if (use_plan) {
+    if (use_plan) { // the pose boxes do not need the map: in front of the join
         const int groups = (h->n + 63) / 64;
         const size_t rows = (size_t)groups * h->nb;
         if (rows > h->plan_rows) {
@@ -1231,6 +1221,19 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             h->plan_rows = rows;
         }
         hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box);
+    }
+    CHK(join_map(h)); // from here on the scoring pass reads the map (lane order and pose boxes above did not)
+    hipEvent_t t_a = nullptr, t_b = nullptr;
+    if (h->timing && !census) {
+        CHK(timer_event(h, &t_a));
+        CHK(timer_event(h, &t_b));
+        HIPCHK(hipEventRecord(t_a, h->stream));
+    }
+    // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
+    // (2.387 vs 2.400 ms with 256-thread groups)
+    const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
+    if (use_plan) {
+        const int groups = (h->n + 63) / 64;
         hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                            (const float *)h->scan, h->nb, kd_view(h), h->plan);
         if (t_a) { // the planning launches are timed on their own: t_a .. t_p; t_p .. t_b brackets the scan-match kernel only

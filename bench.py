@@ -5,7 +5,7 @@
 
 A "step" is one full particleFilter() frame of the KD / point-cloud path (kernel.cu:1702-1762): dispersion,
 1081-beam scan-match of every particle against the KD map, min/max/argmax + weight update, single-step ICP/SVD
-pose, Bresenham map update (with host insert of new walls), Neff + weighted resample.  Workload (BASELINE.json
+pose, Bresenham map update (with the insert of the new walls, on the device), Neff + weighted resample.  Workload (BASELINE.json
 north_star / configs[2], synthetic because data/train_lidar*.mat is absent from the reference checkout):
 100 000 particles per GPU x 1081-beam synthetic scans against a 100 000-point KD map.  Particles shard over the
 GPUs (weak scaling); the map and scan are replicated; the merges are tiny RCCL collectives.

@@ -54,6 +54,10 @@ while time.time() < t_end:
     except pkg.PfSlamError as e:
         print("create refused", desc, e); continue
     drift = rng.rand() < 0.2  # push the particle cloud towards the map edge
+    lag = int(rng.choice([0, 1, 1, 2]))   # frames pfslam_step may leave in flight
+    stride = int(rng.choice([1, 1, 3]))  # the product's trace is read every `stride` frames: in between, frames really are in flight
+    h.set_lag(lag)
+    desc.update(lag=lag, stride=stride)
     ok = True
     for f, (_, scan) in enumerate(frames, start=1):
         scan = mutate(np.ascontiguousarray(scan[:nb]), rng)
@@ -65,7 +69,8 @@ while time.time() < t_end:
                 o.step_grid(f, scan); h.step_grid(f, scan)
             else:
                 o.step(f, scan); h.step(f, scan)
-            h.synchronize()  # pfslam_step only enqueues the frame: a deferred error is reported by the call that books it
+            if f % stride == 0 or f == len(frames):
+                h.synchronize()  # pfslam_step only enqueues the frame: a deferred error is reported by the call that books it
         except pkg.PfSlamError as e:
             # the only legitimate refusal: map capacity exhausted -- the product fails loudly where the oracle (like the
             # reference, which has no bound check at all) just stops inserting; the case ends there
@@ -73,7 +78,16 @@ while time.time() < t_end:
                 ok = False
                 break
             print("UNEXPECTED ERROR", desc, f, e); sys.exit(2)
-        to, tg = o.trace(), h.trace()
+        if not (f % stride == 0 or f == len(frames)):
+            frames_total += 1
+            continue
+        try:
+            to, tg = o.trace(), h.trace()
+        except pkg.PfSlamError as e:
+            if "kd_capacity exhausted" in str(e):
+                ok = False
+                break
+            print("UNEXPECTED ERROR", desc, f, e); sys.exit(2)
         same = (tg == to) or (np.isnan(to["neff"]) and np.isnan(tg["neff"]) and {k: v for k, v in tg.items() if k != "neff"} == {k: v for k, v in to.items() if k != "neff"})
         if not same or not (bits(h.pose) == bits(o.pose)).all():
             print("DIVERGED", desc, "frame", f, tg, to, h.pose, o.pose); sys.exit(1)

@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- particle-scan evaluations per second of the MI355X particle-filter SLAM step.
 
-  python bench.py --gpus N --steps K --warmup W       (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: either started by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+      (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or started plainly -- then bench.py launches its own N ranks
+      (one child process per GPU with the same environment variables set) and relays rank 0's line.
 
 A "step" is one full particleFilter() frame of the KD / point-cloud path (kernel.cu:1702-1762): dispersion,
 1081-beam scan-match of every particle against the KD map, min/max/argmax + weight update, single-step ICP/SVD
 pose, Bresenham map update (with the insert of the new walls, on the device), Neff + weighted resample.  Workload (BASELINE.json
 north_star / configs[2], synthetic because data/train_lidar*.mat is absent from the reference checkout):
 100 000 particles per GPU x 1081-beam synthetic scans against a 100 000-point KD map.  Particles shard over the
-GPUs (weak scaling); the map and scan are replicated; the merges are tiny RCCL collectives.
+GPUs (weak scaling); the map and scan are replicated; the merges are three small RCCL all-gathers per frame.
 BASELINE configs[3]'s per-GPU share is `--particles 125000 --map-points 500000`.
 
 One JSON line on rank 0:  value = particles scored per second over the whole job, with the map, particles and
 all state resident in HBM (the 4.3 KB scan per frame is the step API's input and is inside the timed region).
 
-"roofline" prices the dominant kernel (k_score_kd) against the resource that binds it -- the CU's gather path (texture
-addresser: 4 lane addresses per clock for 64-bit and wider loads, i.e. 64 B/clk per CU for the 16-byte node records) --
-with everything measured in this run: the kernel time by HIP events around the timed launches, the gathers it issues by
-a counting instantiation of the same kernel (pfslam_score_census) before and after the timed region, the chip's gather
-rate by a micro-benchmark (pfslam_ubench_gather).  Sub-blocks: "hbm" = counter bytes of the newest matching rocprofv3 PMC
-summary under profiles/ (never a fixed file) against the 8 TB/s HBM peak; "alg_equiv" = SURVEY 8d's algorithmic bytes
-(B_valid x V x 32 B + 20 B per evaluation), which are L1/L2 hits and therefore NOT a fraction of anything.
+"roofline" prices the dominant kernel (the scan-match kernel) against the resource that binds it -- the CU's gather path (texture
+addresser: 4 lane addresses per clock for 64-bit and wider loads, i.e. 64 B/clk per CU for the 16-byte node records).
+Everything in it is measured on THE TIMED LAUNCHES: the kernel time by HIP events around them, the gathers they issue by a
+REPLAY -- a second handle steps through the same frames (the frame loop is deterministic: same particles, scans and map bit for
+bit, checked) with the counting instantiation of the kernel run behind every scoring pass (pfslam_set_census) --, the chip's
+gather rate by a micro-benchmark (pfslam_ubench_gather).  `frac` is stated against that measured rate AND against the nominal
+256 CU x 64 B/clk x clock.  Sub-blocks: "pmc" = counters of the newest matching rocprofv3 summary under profiles/ (never a
+fixed file): HBM bytes against the 8 TB/s peak, TA busy, and TA_BUFFER_READ_WAVEFRONTS, which must agree with the census;
+"alg_equiv" = SURVEY 8d's algorithmic bytes (B_valid x V x 32 B + 20 B per evaluation), which are L1/L2 hits and therefore NOT a
+fraction of anything.
 "cpu_baseline" times the CPU oracle's restatement of the same scoring loop on this box's usable host cores (a reported
-baseline, not the target); "long_run" is the same step over a whole 100-frame KDTree::Balance cycle.
+baseline, not the target); "long_run" is the same step over a whole 100-frame KDTree::Balance cycle (its rate is also the
+line's third key, `value_long_run`).
 """
 import argparse
 import glob
@@ -30,6 +37,8 @@ import importlib
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -213,14 +222,49 @@ def extras(pkg, O, tree, pts, scan, device):
     return ex
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (what torch.distributed.run would do: one
+    process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) and wait for them.  Rank 0 prints the
+    line; the children inherit stdout / stderr."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PFSLAM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0:          # one rank failed: the others would wait in a collective forever
+                    rc = rc or r
+                    for q in procs:
+                        q.kill()
+            time.sleep(0.05)
+    finally:
+        for q in procs:             # only ever the exact children started above
+            q.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(a.gpus, 1):
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start bench.py plainly (it launches its own ranks) or with "
+                         "`python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...`" % (a.gpus, world, a.gpus, a.gpus))
     pkg = importlib.import_module("gpu-icp-slam_amd")
     if pkg.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: libpfslam_hip.so has no CPU fallback")
@@ -254,17 +298,25 @@ def main():
         scans = list(pool.map(one_scan, range(n_frames)))
 
     cap = a.map_points + (1 << 18)
-    if distributed:
-        from importlib import import_module
-        sharded = import_module("gpu-icp-slam_amd.sharded")
-        eng = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch)
-        eng.want_best = False
-    else:
-        eng = pkg.PfSlam(n_local, kd_capacity=cap, device=local_rank)
+
+    def make_engine():
+        if distributed:
+            from importlib import import_module
+            sharded = import_module("gpu-icp-slam_amd.sharded")
+            e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch)
+        else:
+            e = pkg.PfSlam(n_local, kd_capacity=cap, device=local_rank)
+        e.set_map(tree)
+        if a.variant:
+            e.set_variant(a.variant)
+        # initial condition: a particle cloud already dispersed around the start pose (5 dispersion steps), so that the
+        # first scoring launches behave like steady state instead of scoring 100 k coincident particles
+        for f in range(1, 6):
+            e.motion_update(f)
+        return e
+
+    eng = make_engine()
     e0 = eng.eng if hasattr(eng, "eng") else eng
-    eng.set_map(tree)
-    if a.variant:
-        eng.set_variant(a.variant)
 
     def barrier():
         eng.synchronize()
@@ -285,22 +337,32 @@ def main():
             dt = float(t.item())
         return dt
 
-    # initial condition: a particle cloud already dispersed around the start pose (5 dispersion steps), so that the
-    # first scoring launches behave like steady state instead of scoring 100 k coincident particles
-    for f in range(1, 6):
-        eng.motion_update(f)
     frame = FIRST_FRAME
     for k in range(a.warmup):
         eng.step(frame, scans[k]); frame += 1
     barrier()
-    census0 = e0.score_census() if rank == 0 else None   # what a scoring launch issues on the state the timed region starts from
     eng.set_timing(1)
     dt = timed(a.warmup, a.steps, frame)
     frame += a.steps
     timers = eng.timers()
     eng.set_timing(0)
     trace = eng.trace()
-    census1 = e0.score_census() if rank == 0 else None   # ... and on the state it ends with
+    pose_timed = np.array(eng.pose, np.float32)
+
+    # ---- census replay: what exactly did the timed launches issue?  A second handle steps through the same frames -- the frame
+    # loop is deterministic, so its particles, scans and map are the timed run's, bit for bit (checked on the pose) -- with the
+    # counting instantiation of the scan-match kernel behind every scoring pass (pfslam_set_census).  Every rank takes part.
+    rep = make_engine()
+    r0 = rep.eng if hasattr(rep, "eng") else rep
+    r0.set_census(True)
+    for k in range(a.warmup + a.steps):
+        rep.step(FIRST_FRAME + k, scans[k])
+    rep.synchronize()
+    census_all = r0.census_log()
+    replay_identical = bool((np.array(rep.pose, np.float32).view(np.int32) == pose_timed.view(np.int32)).all())
+    r0.set_census(False)
+    r0.close()
+    del rep, r0
 
     out = None
     if rank == 0:
@@ -308,7 +370,7 @@ def main():
         value = n_global * a.steps / dt
         out = {
             "metric": "particle-scan evals/sec (1081 beams x N particles), full particleFilter step, KD path",
-            "value": value, "unit": "particle-scan evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "value_long_run": None, "unit": "particle-scan evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic 1081-beam scans, %d particles/GPU, %d-point KD map, full SLAM step "
@@ -333,64 +395,84 @@ def main():
         plan_ms = timers["plan_ms"] / max(timers["plan_count"], 1)
         plan_stats = e0.plan_stats()
         ub = e0.ubench_gather()
-        # wave-level gathers per launch: mean of the census before and after the timed region.  A descent-loop trip is one
-        # 16-byte wave gather; a parent-hyperplane test one 16-byte + one 4-byte wave gather.
-        g16 = 0.5 * ((census0["trips"] + census0["tests"]) + (census1["trips"] + census1["tests"]))
-        g4 = 0.5 * (census0["tests"] + census1["tests"])
-        lane_visits = 0.5 * (census0["visits"] + census1["visits"])
-        gather_bytes = g16 * 64 * 16 + g4 * 64 * 4           # lane-level bytes the TA path moves per launch
+        # wave-level gathers per launch, from the replay's census of the SAME launches.  A descent-loop trip is one 16-byte wave
+        # gather; a parent-hyperplane test one 16-byte + one 4-byte wave gather.  Bytes are lane-level: 64 lanes x record size.
+        cen_timed = census_all[a.warmup:a.warmup + a.steps]
+
+        def per_launch(c):
+            g16, g4 = c["trips"] + c["tests"], c["tests"]
+            return g16, g4, g16 * 64 * 16 + g4 * 64 * 4
+
+        pl = [per_launch(c) for c in cen_timed] or [(0, 0, 0)]
+        g16 = float(np.mean([v[0] for v in pl])); g4 = float(np.mean([v[1] for v in pl]))
+        gbytes = [v[2] for v in pl]
+        gather_bytes = float(np.mean(gbytes))                  # lane-level bytes the TA path moves per launch
+        lane_visits = float(np.mean([c["visits"] for c in cen_timed])) if cen_timed else 0.0
+        trips = float(np.mean([c["trips"] for c in cen_timed])) if cen_timed else 0.0
         achieved = gather_bytes / kern_s / 1e9
         peak_measured = ub["wave_gathers_per_s"] * 1024.0 / 1e9
-        peak_nominal = ub["cus"] * 64.0 * ub["nominal_ghz"]  # 64 B/clk per CU (4 lanes x 16 B) at the nominal clock, GB/s
         pmc_path = find_pmc(a.pmc_file, n_local, a.map_points)
-        traffic, clock_ghz, pmc = None, None, None
+        traffic, clock_ghz, pmc, avgp = None, None, None, {}
         if pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
+                avgp = pmc.get("avg_per_launch", {})
                 traffic = pmc.get("hbm_bytes_per_launch")
-                gui = pmc.get("avg_per_launch", {}).get("GRBM_GUI_ACTIVE")
-                kms = pmc.get("kernel_ms")
-                if gui and kms:
+                clock_ghz = pmc.get("measured_clock_ghz")
+                gui, kms = avgp.get("GRBM_GUI_ACTIVE"), pmc.get("kernel_ms")
+                if not clock_ghz and gui and kms:                # summaries of rounds 1-2
                     clock_ghz = gui / 8.0 / (kms * 1e-3) / 1e9   # GRBM_GUI_ACTIVE sums the 8 XCDs
             except Exception:
-                traffic = None
+                traffic, pmc, avgp = None, None, {}
+        ghz = clock_ghz or ub["nominal_ghz"]
+        peak_nominal = ub["cus"] * 64.0 * ghz                  # 64 B/clk per CU (4 lanes x 16 B), GB/s
         alg_bytes_per_eval = bvalid * vbar * 32.0 + 20.0     # B_valid x V x 32 B + 16 B in + 4 B out
+        ta_wf = avgp.get("TA_BUFFER_READ_WAVEFRONTS_sum")
         out["roofline"] = {
             "bound": "l1_gather", "achieved": achieved, "peak": peak_measured, "unit": "GB/s", "frac": achieved / peak_measured,
             "traffic": traffic,
+            "frac_of_nominal_peak": achieved / peak_nominal,
+            "peak_nominal": peak_nominal, "peak_nominal_clock_ghz": ghz,
+            "peak_nominal_clock_source": ("GRBM_GUI_ACTIVE / 8 / kernel time of " + os.path.relpath(pmc_path, ROOT)) if clock_ghz else "nominal clock (hipDeviceProp)",
             "kernel": "k_score_kd_plan" if plan_stats["rows"] else "k_score_kd", "kernel_ms": kern_s * 1e3, "launches": launches,
             "kernel_evals_per_s": n_local / kern_s,
+            "census": {"launches": len(cen_timed), "replay_identical": replay_identical,
+                       "gather_bytes_per_launch": {"min": float(min(gbytes)), "mean": gather_bytes, "max": float(max(gbytes))},
+                       "wave_gathers_16B_per_launch": g16, "wave_gathers_4B_per_launch": g4,
+                       "wave_gathers_per_launch": g16 + g4,
+                       "lane_visits_per_launch": lane_visits, "lanes_active_per_trip": lane_visits / max(trips, 1.0),
+                       "first": cen_timed[0] if cen_timed else None, "last": cen_timed[-1] if cen_timed else None,
+                       "oracle_min_wave_gathers": n_local / 64.0 * bvalid * vbar,
+                       "note": "counted on the timed launches themselves: a second handle replays frames %d..%d (bit-identical state, "
+                               "`replay_identical`) with the counting instantiation of the kernel behind every scoring pass; "
+                               "wave_gathers_per_launch = trips + 2 x tests = what TA_BUFFER_READ_WAVEFRONTS_sum counts for the same "
+                               "launches (pmc.census_over_pmc_wavefronts)" % (FIRST_FRAME, FIRST_FRAME + a.warmup + a.steps - 1)},
             "plan": dict(plan_stats, kernel_ms=plan_ms,
                          note="shared-prefix plan of the LAST timed launch (pfslam_plan_stats): one planning lane per (wave, beam) walks "
                               "the root path common to the wave's 64 queries and keeps only the nodes that can be nearest for some "
                               "lane; kernel_ms = k_group_box + k_plan, which run before the scan-match kernel"),
-            "definition": "achieved = lane-level bytes of the wave gathers one launch issues (16 B x 64 lanes per node-record gather, "
-                          "4 B x 64 per parent-index gather; counted by pfslam_score_census before and after the timed region, mean) / "
-                          "HIP-event time of the timed launches; peak = wave-gather rate of this chip measured in this process "
-                          "(pfslam_ubench_gather: cache-resident table, 8 waves/SIMD) x 1024 B.  With the shared-prefix plan most node "
-                          "visits are evaluated from scalar registers and issue no gather at all, and the gathers that remain are the "
-                          "divergent ones (several cache lines each), so this fraction is a LOWER bound of the gather path's load: the "
-                          "PMC sub-block `ta_busy` has the counter",
-            "gathers": {"wave_gathers_16B_per_launch": g16, "wave_gathers_4B_per_launch": g4, "lane_visits_per_launch": lane_visits,
-                        "lanes_active_per_trip": lane_visits / max(0.5 * (census0["trips"] + census1["trips"]), 1.0),
-                        "census_before": census0, "census_after": census1,
-                        "oracle_min_wave_gathers": n_local / 64.0 * bvalid * vbar},
-            "ubench": dict(ub, peak_nominal_GBs=peak_nominal,
-                           note="peak_nominal = CUs x 64 B/clk x nominal clock; the measured rate is what the same "
-                                "gather instruction sustains on this box"),
-            "frac_of_nominal_peak": achieved / peak_nominal,
-            "ta_busy": None if not (pmc and pmc.get("avg_per_launch", {}).get("TA_TA_BUSY_sum") and pmc.get("avg_per_launch", {}).get("GRBM_GUI_ACTIVE")) else {
-                "frac": pmc["avg_per_launch"]["TA_TA_BUSY_sum"] / ub["cus"] / (pmc["avg_per_launch"]["GRBM_GUI_ACTIVE"] / 8.0),
-                "valu_insts_per_simd_cycle": (pmc["avg_per_launch"].get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (pmc["avg_per_launch"]["GRBM_GUI_ACTIVE"] / 8.0),
-                "source": os.path.relpath(pmc_path, ROOT),
-                "note": "TA_TA_BUSY_sum / CUs / (GRBM_GUI_ACTIVE / 8 XCDs): fraction of the kernel's cycles the texture addressers were "
-                        "busy; VALU wave-instructions per SIMD per cycle next to it (a wave64 VALU instruction occupies 2-4 cycles)"},
-            "hbm": None if traffic is None else {
-                "bytes_per_launch": traffic, "achieved": traffic / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS, "source": os.path.relpath(pmc_path, ROOT),
-                "measured_clock_ghz": clock_ghz,
-                "note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes (gfx950 correction of MI355X_MICROARCH.md); the map "
-                        "records are cache resident, compulsory HBM traffic is ~20 B per evaluation + the beam-chunk partials"},
+            "definition": "achieved = lane-level bytes of the wave gathers one timed launch issues (16 B x 64 lanes per node-record gather, "
+                          "4 B x 64 per parent-index gather; census of the timed launches, mean) / HIP-event time of the same launches "
+                          "(mean); peak = wave-gather rate of this chip measured in this process (pfslam_ubench_gather: cache-resident "
+                          "table, 8 waves/SIMD) x 1024 B; frac_of_nominal_peak prices the same bytes against CUs x 64 B/clk x clock.  "
+                          "With the shared-prefix plan most node visits are evaluated from scalar registers and issue no gather at all, "
+                          "and the gathers that remain are the divergent ones (several cache lines each), so `frac` is a LOWER bound "
+                          "of the gather path's load: pmc.ta_busy has the counter",
+            "ubench": dict(ub, note="the measured rate is what the same gather instruction sustains on this box, wave-uniform addresses"),
+            "pmc": None if not pmc else {
+                "source": os.path.relpath(pmc_path, ROOT), "measured_clock_ghz": clock_ghz,
+                "ta_buffer_read_wavefronts_per_launch": ta_wf,
+                "census_over_pmc_wavefronts": ((g16 + g4) / ta_wf) if ta_wf else None,
+                "ta_busy": (avgp["TA_TA_BUSY_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_TA_BUSY_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
+                "ta_cycles_frac": (avgp["TA_BUFFER_TOTAL_CYCLES_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_BUFFER_TOTAL_CYCLES_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
+                "valu_insts_per_simd_cycle": ((avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
+                "hbm": None if traffic is None else {"bytes_per_launch": traffic, "achieved": traffic / kern_s / 1e9, "peak": HBM_PEAK_GBS,
+                                                     "unit": "GB/s", "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS},
+                "note": "rocprofv3 PMC passes of `python bench.py --no-cpu-baseline` (tools/profile_round.sh), averaged over the TIMED "
+                        "launches of that process (dispatches [warmup, warmup + steps) of the timed instantiation).  ta_busy = TA_TA_BUSY_sum / CUs / (GRBM_GUI_ACTIVE / 8 XCDs); "
+                        "ta_cycles_frac = TA_BUFFER_TOTAL_CYCLES_sum / CUs / kernel cycles; hbm = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 "
+                        "correction of MI355X_MICROARCH.md) -- the map records are cache resident, compulsory HBM traffic is ~20 B per "
+                        "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement)"},
             "alg_equiv": {"bytes_per_eval": alg_bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                           "GBs": alg_bytes_per_eval * n_local / kern_s / 1e9,
                           "note": "SURVEY 8d's algorithmic node bytes (B_valid x V x 32 B + 20 B): served from L1/L2, "
@@ -407,6 +489,7 @@ def main():
             dtl = timed(k, 100, frame)
             frame += 100; k += 100
             if out is not None:
+                out["value_long_run"] = n_global * 100 / dtl
                 out["long_run"] = {"frames": 100, "first_frame": frame - 100, "ms_per_step": dtl / 100 * 1e3,
                                    "value": n_global * 100 / dtl, "unit": "particle-scan evals/s",
                                    "includes": "one KDTree::Balance (host re-build + upload of the whole map, kernel.cu:1707-1711) "

@@ -17,14 +17,14 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_begin", "pfslam_shard_weights", "pfslam_shard_map", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_disperse", "pfslam_shard_score", "pfslam_shard_weights", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_ubench_gather", "pfslam_plan_stats",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats",
 ]
 
 
@@ -91,10 +91,10 @@ def load():
     L.pfslam_synchronize.argtypes = [vp]
     L.pfslam_step.argtypes = [vp, i32, vp]
     L.pfslam_step_grid.argtypes = [vp, i32, vp]
-    L.pfslam_shard_begin.argtypes = [vp, i32, vp, vp]
-    L.pfslam_shard_finish.argtypes = [vp, i32, vp, vp]
-    L.pfslam_shard_map.argtypes = [vp]
+    L.pfslam_shard_disperse.argtypes = [vp, i32, vp, vp]
+    L.pfslam_shard_score.argtypes = [vp]
     L.pfslam_shard_weights.argtypes = [vp]
+    L.pfslam_shard_finish.argtypes = [vp]
     L.pfslam_get_pose.argtypes = [vp, vp]
     L.pfslam_get_particles.argtypes = [vp, vp, vp]
     L.pfslam_get_map.argtypes = [vp, vp, vp]
@@ -123,6 +123,8 @@ def load():
     L.pfslam_set_topology.argtypes = [vp, i32]
     L.pfslam_get_closures.argtypes = [vp, vp, i32, vp]
     L.pfslam_score_census.argtypes = [vp, vp]
+    L.pfslam_set_census.argtypes = [vp, i32]
+    L.pfslam_get_census_log.argtypes = [vp, vp, i32, vp]
     L.pfslam_ubench_gather.argtypes = [vp, vp]
     L.pfslam_plan_stats.argtypes = [vp, vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
@@ -359,6 +361,17 @@ class PfSlam:
         return {"trips": int(out[0]), "visits": int(out[1]), "tests": int(out[2]), "test_lanes": int(out[3]),
                 "uniform_trips": int(out[4]), "prefix_trips": int(out[5]), "redescents": int(out[6]), "redescents_noop": int(out[7])}
 
+    def set_census(self, enable=True):
+        """Log what every scoring pass issues (counting instantiation on the same inputs, see include/pfslam.h)."""
+        _chk(self.L.pfslam_set_census(self._h, int(enable)), "pfslam_set_census")
+
+    def census_log(self, cap=1024):
+        out = np.zeros((cap, 8), np.uint64)
+        n = C.c_int()
+        _chk(self.L.pfslam_get_census_log(self._h, _p(out), cap, C.byref(n)), "pfslam_get_census_log")
+        keys = ("trips", "visits", "tests", "test_lanes", "uniform_trips", "prefix_trips", "redescents", "redescents_noop")
+        return [dict(zip(keys, (int(v) for v in row))) for row in out[:min(n.value, cap)]]
+
     def plan_stats(self):
         out = (C.c_double * 10)()
         _chk(self.L.pfslam_plan_stats(self._h, out), "pfslam_plan_stats")
@@ -390,23 +403,21 @@ class PfSlam:
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         _chk(self.L.pfslam_step(self._h, frame, _p(scan)), "pfslam_step")
 
-    def shard_begin(self, frame, scan):
-        """Sharded frame, first half (see include/pfslam.h); returns True when the frame only seeded the map."""
+    def shard_disperse(self, frame, scan):
+        """Sharded frame (see include/pfslam.h): scan, re-balance, ICP fork, dispersion; True when the frame only seeded the map."""
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         seeded = C.c_int(0)
-        _chk(self.L.pfslam_shard_begin(self._h, frame, _p(scan), C.byref(seeded)), "pfslam_shard_begin")
+        _chk(self.L.pfslam_shard_disperse(self._h, frame, _p(scan), C.byref(seeded)), "pfslam_shard_disperse")
         return bool(seeded.value)
+
+    def shard_score(self):
+        _chk(self.L.pfslam_shard_score(self._h), "pfslam_shard_score")
 
     def shard_weights(self):
         _chk(self.L.pfslam_shard_weights(self._h), "pfslam_shard_weights")
 
-    def shard_map(self):
-        _chk(self.L.pfslam_shard_map(self._h), "pfslam_shard_map")
-
-    def shard_finish(self, frame):
-        did, neff = C.c_int(0), C.c_float(0)
-        _chk(self.L.pfslam_shard_finish(self._h, frame, C.byref(did), C.byref(neff)), "pfslam_shard_finish")
-        return did.value, neff.value
+    def shard_finish(self):
+        _chk(self.L.pfslam_shard_finish(self._h), "pfslam_shard_finish")
 
     def step_grid(self, frame, scan):
         """One frame of the 2-D occupancy-grid variant (motion, grid score + weights, grid update, resample)."""

@@ -33,6 +33,7 @@
 #define PF_SCAN_TILE 1024
 #define PF_SCAN_CHUNK 16
 enum { PF_T_SCORE = 0, PF_T_MOTION, PF_T_MEASURE, PF_T_MAP, PF_T_RESAMPLE, PF_T_PLAN, PF_TIMER_SLOTS };
+#define PF_CENSUS_LOG 1024 /* scoring passes pfslam_set_census keeps a record of */
 #define PF_KD_MAX_NODES ((1 << 27) - 1) /* idx << 4 must fit the 0x7ffffff0-byte buffer descriptor; links are 30-bit */
 
 static thread_local std::string g_err;
@@ -148,6 +149,8 @@ struct pfslam_handle {
     struct Frame { int seq, frame, kind; };          // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once)
     std::deque<Frame> in_flight;
     int seq = 0; // tickets handed out
+    int cur_seq = 0, cur_frame = 0; // the frame being enqueued (frame_front .. frame_tail)
+    int shard_stage = 0;            // sharded frame: 1 dispersed, 2 scored, 3 weights done (call order check)
     int lag = 1; // frames the host may run ahead (PFSLAM_LAG; 0 = every step settles itself)
     float scan_reach = 8.0f; // mean in-range beam length of the current scan (m): the lever arm of a heading difference
     std::vector<pfslam_particle> h_particles;
@@ -160,7 +163,6 @@ struct pfslam_handle {
     hipEvent_t ev_mapfork = nullptr, ev_map = nullptr; // map update of a frame on the aux stream (join_map)
     bool map_forked = false;
     bool scan_front_done = false; // tile totals and offsets of the resample scan were produced with the weight sums of this frame
-    bool shard_map_done = false;  // pfslam_shard_map already launched this frame's map-update chain
     bool header_packed = false;   // k_test_new already filled the frame's HostHeader
     bool lds_attr_set = false;    // k_test_new's dynamic LDS limit raised (scans of more than 1536 beams)
     bool mirror_stale = false;    // the device has inserted nodes since h_nodes was last made current
@@ -180,6 +182,8 @@ struct pfslam_handle {
     double timer_ms[PF_TIMER_SLOTS] = {0};
     long timer_count[PF_TIMER_SLOTS] = {0};
     pf::KdCensus *d_census = nullptr;
+    pf::KdCensus *census_store = nullptr, *census_log = nullptr; // pfslam_set_census: one record per scoring pass
+    int census_n = 0;
     // shared-prefix plan of the score kernel: one row per (wave of 64 lanes, beam), pose box per wave
     pf::KdPlanRow *plan = nullptr;
     size_t plan_rows = 0;
@@ -295,7 +299,10 @@ __global__ __launch_bounds__(64) void k_plan(const pf::KdGroupBox *__restrict__ 
     // (|cy| + |r| d) d in x and (|cx| + |r| d) d in y; eps covers the lanes' float rounding and the 1-ulp sincos many times over
     float cx, cy;
     pf::clean_lidar_scan(j, r, tc, cx, cy);
-    const float dd = dth + 1e-6f, eps = 2e-4f + 1e-5f * fabsf(r);
+    // ... and the rounding of rot = angle + theta itself, which grows with |theta| (headings are never normalised): the centre and
+    // every lane each round their own sum to 0.5 ulp(|rot|) <= 2^-24 (|theta| + 2.36), i.e. up to |r| * 2 ulp of end-point motion
+    const float dd = dth + 1e-6f;
+    const float eps = 2e-4f + 1e-5f * fabsf(r) + fabsf(r) * 2.0f * 1.1920929e-7f * (fabsf(tc) + 2.4f + dd);
     const float hx = (fabsf(cy) + fabsf(r) * dd) * dd + eps, hy = (fabsf(cx) + fabsf(r) * dd) * dd + eps;
     const float wxlo = b.xlo + cx - hx, wxhi = b.xhi + cx + hx, wylo = b.ylo + cy - hy, wyhi = b.yhi + cy + hy;
     int n_cand = 0, resume = 0, path_len = 0;
@@ -816,6 +823,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); if (!e.keep_b) (void)hipEventDestroy(e.b); }
     if (h->phase_ev) (void)hipEventDestroy(h->phase_ev);
     if (h->d_census) (void)hipFree(h->d_census);
+    if (h->census_store) (void)hipFree(h->census_store);
     if (h->plan) (void)hipFree(h->plan);
     if (h->group_box) (void)hipFree(h->group_box);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1232,6 +1240,28 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
     // (2.387 vs 2.400 ms with 256-thread groups)
     const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
+    // the scan-match kernel itself; cen != nullptr: its counting instantiation (same launch shape, lane order, plan and results)
+    auto scan_match = [&](pf::KdCensus *cen) {
+        if (use_plan) {
+            if (cen)
+                hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                                   kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, cen);
+            else
+                hipLaunchKernelGGL((k_score_kd_plan<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                                   kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, (pf::KdCensus *)nullptr);
+        } else if (h->planar && cen)
+            hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                               kd_view(h), order, direct, out, cen);
+        else if (cen)
+            hipLaunchKernelGGL((k_score_kd<false, true>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                               kd_view(h), order, direct, out, cen);
+        else if (h->planar)
+            hipLaunchKernelGGL((k_score_kd<true, false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                               kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
+        else
+            hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                               kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
+    };
     if (use_plan) {
         const int groups = (h->n + 63) / 64;
         hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
@@ -1243,28 +1273,17 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             h->ev_pending.push_back(pfslam_handle::TimedSpan{t_a, t_p, PF_T_PLAN, /*keep_b=*/true});
             t_a = t_p;
         }
-        if (census)
-            hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                               kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, census);
-        else
-            hipLaunchKernelGGL((k_score_kd_plan<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                               kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, (pf::KdCensus *)nullptr);
-    } else if (h->planar && census)
-        hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                           kd_view(h), order, direct, out, census);
-    else if (census)
-        hipLaunchKernelGGL((k_score_kd<false, true>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                           kd_view(h), order, direct, out, census);
-    else if (h->planar)
-        hipLaunchKernelGGL((k_score_kd<true, false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                           kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
-    else
-        hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                           kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
+    }
+    scan_match(census);
     HIPCHK(hipGetLastError());
     if (t_a) {
         HIPCHK(hipEventRecord(t_b, h->stream));
         h->ev_pending.push_back(pfslam_handle::TimedSpan{t_a, t_b, PF_T_SCORE});
+    }
+    // census log (pfslam_set_census): the counting instantiation once more on the very same inputs, one record per scoring pass
+    if (h->census_log && !census && h->census_n < PF_CENSUS_LOG) {
+        scan_match(h->census_log + h->census_n++);
+        HIPCHK(hipGetLastError());
     }
     if (fuse_minmax) {
         if (h->icp_forked) CHK(join_icp(h)); // the aux stream reset the keys
@@ -1316,6 +1335,40 @@ extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[8])
     HIPCHK(hipMemcpyAsync(&c, h->d_census, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     out[0] = c.trips; out[1] = c.lanes; out[2] = c.tests; out[3] = c.test_lanes; out[4] = c.uniform; out[5] = c.prefix; out[6] = c.redesc; out[7] = c.redesc_noop;
+    return 0;
+}
+
+// Census log: while enabled, every scoring pass (pfslam_step, pfslam_shard_score, pfslam_score_kd) is followed by the counting
+// instantiation of the scan-match kernel on the very same inputs (particles, scan, map, lane order, plan); one record per pass.
+// This is how bench.py counts what its TIMED launches issue: a second handle replays the same frames with the log on.
+extern "C" int pfslam_set_census(pfslam_handle *h, int enable)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (enable) {
+        if (!h->census_store) CHK(dalloc(&h->census_store, (size_t)PF_CENSUS_LOG));
+        HIPCHK(hipMemsetAsync(h->census_store, 0, sizeof(pf::KdCensus) * PF_CENSUS_LOG, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->census_n = 0;
+    }
+    h->census_log = enable ? h->census_store : nullptr;
+    return 0;
+}
+// out[k][0..7] = {trips, lanes, tests, test_lanes, uniform, prefix, redescents, redescents_noop} of the k-th logged pass
+extern "C" int pfslam_get_census_log(pfslam_handle *h, unsigned long long *out, int cap, int *n)
+{
+    if (!h || !n || (cap > 0 && !out)) return fail("pfslam_get_census_log: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    *n = h->census_n;
+    const int m = std::min(h->census_n, cap);
+    if (m > 0 && h->census_store) {
+        static_assert(sizeof(pf::KdCensus) == 64, "eight counters per record");
+        HIPCHK(hipMemcpyAsync(out, h->census_store, (size_t)m * sizeof(pf::KdCensus), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 
@@ -1514,7 +1567,9 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
 extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes)
 {
     if (!h || !ptr || !bytes) return fail("pfslam_device_ptr: bad argument");
-    CHK(settle(h));
+    // no settle: the buffers are fixed for the handle's lifetime, except the pose blocks 2-4 / 16 (and 17 on an unsharded handle),
+    // which alternate between two allocations with every enqueued frame -- the pointer returned is the one the NEXT enqueued
+    // kernel will use, which is what a caller placing collectives between the pfslam_shard_* calls needs
     const size_t n = h->n;
     switch (which) {
     case 0: *ptr = h->stats; *bytes = 64; break;

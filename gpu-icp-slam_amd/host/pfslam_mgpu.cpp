@@ -1,6 +1,6 @@
 // pfslam_mgpu.cpp -- multi-GPU driver in C++ on librccl directly: one process per GPU, particles sharded over the ranks,
-// map / scan / ICP / map update replicated, two all-gathers per frame (three in frames that resample) over xGMI.
-// The protocol is the sharded frame of include/pfslam.h (pfslam_shard_begin / weights / map / finish); the Python harness
+// map / scan / ICP / map update replicated, three all-gathers per frame over xGMI on a fixed schedule, no host wait per frame.
+// The protocol is the sharded frame of include/pfslam.h (pfslam_shard_disperse / score / weights / finish); the Python harness
 // gpu-icp-slam_amd/sharded.py runs the same protocol through torch.distributed.
 //
 //   pfslam_mgpu --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX]
@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -146,8 +147,10 @@ static int get_id(int rank, const std::string &path, ncclUniqueId &id)
 {
     if (rank == 0) {
         NCCL(ncclGetUniqueId(&id));
-        const std::string tmp = path + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
+        unlink(path.c_str()); // an id left behind by a run that died (a clean run removes its own, see run_rank)
+        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        FILE *f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
         if (!f || fwrite(&id, sizeof(id), 1, f) != 1) {
             fprintf(stderr, "cannot write %s\n", tmp.c_str());
             return 1;
@@ -161,7 +164,7 @@ static int get_id(int rank, const std::string &path, ncclUniqueId &id)
     }
     for (int tries = 0; tries < 6000; tries++) { // up to 60 s
         struct stat st;
-        if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id)) {
+        if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id) && st.st_uid == getuid()) {
             FILE *f = fopen(path.c_str(), "rb");
             if (f && fread(&id, sizeof(id), 1, f) == 1) {
                 fclose(f);
@@ -185,7 +188,7 @@ static int query(pfslam_handle *h, Buffers &b)
     PF(pfslam_device_ptr(h, 15, &b.packs, &bytes));
     PF(pfslam_device_ptr(h, 5, &b.w, &bytes));
     PF(pfslam_device_ptr(h, 10, &b.gw, &bytes));
-    PF(pfslam_device_ptr(h, 16, &b.pose_blk, &bytes)); // moves when a resample swaps the double buffer
+    PF(pfslam_device_ptr(h, 16, &b.pose_blk, &bytes)); // alternates between two allocations with every frame
     PF(pfslam_device_ptr(h, 17, &b.gpose, &bytes));
     return 0;
 }
@@ -194,37 +197,45 @@ struct Rank {
     pfslam_handle *h = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_w = nullptr, ev_g = nullptr;
-    int stride = 0, collectives = 0;
+    hipEvent_t ev_p = nullptr, ev_pg = nullptr, ev_w = nullptr, ev_wg = nullptr;
+    int stride = 0, world = 1, collectives = 0;
 };
 
-// the sharded frame of include/pfslam.h; ONE host sync (inside pfslam_shard_finish)
+// the sharded frame of include/pfslam.h: three all-gathers on a fixed schedule, NO host wait (the frame is booked one step
+// later from its pinned header, like pfslam_step's)
 static int step(Rank &R, int frame, const float *scan)
 {
     int seeded = 0;
-    PF(pfslam_shard_begin(R.h, frame, scan, &seeded));
+    PF(pfslam_shard_disperse(R.h, frame, scan, &seeded));
     if (seeded) return 0; // the first scan only seeds the (replicated) map
     Buffers b;
     if (query(R.h, b)) return 1;
-    NCCL(ncclAllGather(b.pack, b.packs, 32, ncclChar, R.comm, R.stream)); // keys + pose of every shard's best particle
-    PF(pfslam_shard_weights(R.h));
-    // the weights are final: gather them on the side stream while the replicated map update runs on the main one
-    HIP(hipEventRecord(R.ev_w, R.stream));
-    HIP(hipStreamWaitEvent(R.comm_stream, R.ev_w, 0));
-    NCCL(ncclAllGather(b.w, b.gw, (size_t)R.stride, ncclFloat, R.comm, R.comm_stream));
-    HIP(hipEventRecord(R.ev_g, R.comm_stream));
-    PF(pfslam_shard_map(R.h));
-    HIP(hipStreamWaitEvent(R.stream, R.ev_g, 0));
-    int resampled = 0;
-    float neff = 0.0f;
-    PF(pfslam_shard_finish(R.h, frame, &resampled, &neff));
-    R.collectives += 2;
-    if (resampled) {
-        if (query(R.h, b)) return 1;
-        NCCL(ncclAllGather(b.pose_blk, b.gpose, (size_t)3 * R.stride, ncclFloat, R.comm, R.stream)); // [x | y | theta] in one piece
-        PF(pfslam_resample_gather(R.h));
-        R.collectives += 1;
+    const bool comm = R.world > 1; // world 1: buffers 10 / 17 alias 5 / 16, nothing to move
+    // the poses are final right after the dispersion: gather [x | y | theta] on the side stream, under the score kernel
+    if (comm) {
+        HIP(hipEventRecord(R.ev_p, R.stream));
+        HIP(hipStreamWaitEvent(R.comm_stream, R.ev_p, 0));
+        NCCL(ncclAllGather(b.pose_blk, b.gpose, (size_t)3 * R.stride, ncclFloat, R.comm, R.comm_stream));
+        HIP(hipEventRecord(R.ev_pg, R.comm_stream));
     }
+    PF(pfslam_shard_score(R.h));
+    if (comm) {
+        NCCL(ncclAllGather(b.pack, b.packs, 32, ncclChar, R.comm, R.stream)); // keys + pose of every shard's best particle
+    } else {
+        HIP(hipMemcpyAsync(b.packs, b.pack, 32, hipMemcpyDeviceToDevice, R.stream));
+    }
+    PF(pfslam_shard_weights(R.h));
+    // the weights are final: gather them on the side stream while the replicated map update's lists are built
+    if (comm) {
+        HIP(hipEventRecord(R.ev_w, R.stream));
+        HIP(hipStreamWaitEvent(R.comm_stream, R.ev_w, 0));
+        NCCL(ncclAllGather(b.w, b.gw, (size_t)R.stride, ncclFloat, R.comm, R.comm_stream));
+        HIP(hipEventRecord(R.ev_wg, R.comm_stream));
+        HIP(hipStreamWaitEvent(R.stream, R.ev_pg, 0));
+        HIP(hipStreamWaitEvent(R.stream, R.ev_wg, 0));
+    }
+    PF(pfslam_shard_finish(R.h));
+    R.collectives += 3;
     return 0;
 }
 
@@ -265,11 +276,15 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
     if (get_id(rank, id_file, id)) return 1;
     Rank R;
     NCCL(ncclCommInitRank(&R.comm, world, id, rank));
+    if (rank == 0) unlink(id_file.c_str()); // every rank has joined: a later run must never pick this id up
     HIP(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
     HIP(hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
+    HIP(hipEventCreateWithFlags(&R.ev_p, hipEventDisableTiming));
+    HIP(hipEventCreateWithFlags(&R.ev_pg, hipEventDisableTiming));
     HIP(hipEventCreateWithFlags(&R.ev_w, hipEventDisableTiming));
-    HIP(hipEventCreateWithFlags(&R.ev_g, hipEventDisableTiming));
+    HIP(hipEventCreateWithFlags(&R.ev_wg, hipEventDisableTiming));
     R.stride = stride;
+    R.world = world;
     pfslam_config cfg;
     pfslam_default_config(&cfg);
     cfg.n_particles = count;
@@ -338,7 +353,7 @@ int main(int argc, char **argv)
     std::string id_file = getenv("PFSLAM_ID_FILE") ? getenv("PFSLAM_ID_FILE") : "";
     if (id_file.empty()) {
         const char *port = getenv("MASTER_PORT");
-        id_file = std::string("/tmp/pfslam_nccl_id.") + (port ? port : "0");
+        id_file = std::string("/tmp/pfslam_nccl_id.") + std::to_string((long)getuid()) + "." + (port ? port : "0");
     }
     return run_rank(a, rank, world, local_rank, id_file);
 }

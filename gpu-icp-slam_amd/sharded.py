@@ -1,14 +1,18 @@
 """Multi-GPU stepping: particles shard over the ranks of one node (one process per GPU), the map, the scan,
-the ICP solve and the map update are replicated, and the merges are two small collectives per frame
+the ICP solve and the map update are replicated, and the merges are three all-gathers per frame on a FIXED schedule
 (torch.distributed: backend "nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).  The C++ driver
 host/pfslam_mgpu.cpp runs the same protocol on librccl directly.
 
 Per frame (include/pfslam.h "multi-GPU"):
+    all-gather  of 3 stride x f32       [x | y | theta] in one piece, right after the dispersion: it runs on the collective's
+                                        own stream UNDER the score kernel
     all-gather  of 32 B per rank        {max key, negated-min key, pose of the shard's best particle}: every rank derives the
                                         global min / max / first-occurrence argmax and the best pose from the gathered records
     all-gather  of stride x f32         weights -> global array (Neff, cdf and sampling run on it, replicated); overlapped
                                         with the replicated map update
-    all-gather  of 3 stride x f32       [x | y | theta] in one piece, only in frames that resample
+No call waits for the device and no collective depends on data: the resample is decided ON the device (Neff of the gathered
+weights), its sources are read from the gathered pose blocks, and the frame is booked one step later from its pinned header --
+the sharded frame is the single-GPU pipeline of pfslam_step with three collectives placed in it.
 Rank r owns the global particles [r * stride, min((r + 1) * stride, N)), stride = ceil(N / world): the last shard may be
 shorter, the exchange buffers are padded to `stride`.  Everything that touches randomness is keyed by GLOBAL particle
 indices, and every sum runs on the global array in the canonical order, so the result is bit-identical for any number of
@@ -84,9 +88,7 @@ class ShardedSlam:
                 engine.set_stream(torch.cuda.current_stream().cuda_stream)
             buffers = GpuBuffers(engine, torch, device)
         self.eng, self.buf = engine, buffers
-        self._last = {}
-        self.want_best = True  # trace()['best'] costs one tiny read-back per step; bench.py turns it off
-        self.collectives = 0   # all-gathers issued (2 per frame, 3 in frames that resample)
+        self.collectives = 0   # all-gathers issued: 3 in every frame (fixed schedule)
 
     # -- pass-throughs
     def set_map(self, tree): self.eng.set_map(tree)
@@ -95,7 +97,7 @@ class ShardedSlam:
     def timers(self): return self.eng.timers()
     def motion_update(self, frame): self.eng.motion_update(frame)
     def synchronize(self): self.eng.synchronize()
-    def trace(self): return dict(self._last)
+    def trace(self): return self.eng.trace()   # books the frames in flight first (pfslam_get_trace)
     @property
     def pose(self): return self.eng.pose
 
@@ -110,22 +112,18 @@ class ShardedSlam:
             self.dist.all_gather_into_tensor(dst, src)
 
     def step(self, frame, scan):
-        """One frame; the host synchronises once (in shard_finish), everything else is enqueued."""
+        """One frame, enqueued: nothing here waits for the device (see include/pfslam.h, pfslam_shard_*)."""
         e, b = self.eng, self.buf
-        if e.shard_begin(frame, scan):          # first scan seeds the map (kernel.cu:1714-1717); replicated
-            self._last = {"best": -1, "resampled": 0, "kd_size": e.kd_size}
+        if e.shard_disperse(frame, scan):       # first scan seeds the map (kernel.cu:1714-1717); replicated
             return
+        local, glob = b.pose_blocks()           # the local block alternates between two allocations: ask every frame
+        # the poses are final: gather them now; the collective runs on its own stream under the score kernel
+        p_pose = self._all_gather(glob, local, async_op=True)
+        e.shard_score()                         # lane order, plan, scan-match, reduce -> this shard's 32-byte record
         self._all_gather(b.packs, b.pack)       # 32 bytes per rank: keys + pose of every shard's best particle
-        e.shard_weights()                       # global min / max / argmax, weights, pose = best + ICP increment
-        # the weights are final: gather them while the (replicated) map update runs
-        pending = self._all_gather(b.gw, b.w, async_op=True)
-        e.shard_map()                           # replicated map update (device part): the all-gather runs under it
-        if pending is not None:
-            pending.wait()                      # stream-level: orders the compute stream behind the collective
-        did, neff = e.shard_finish(frame)       # Neff on the global weights, header, the one host sync, resample plan
-        if did:
-            local, glob = b.pose_blocks()
-            self._all_gather(glob, local)       # [x | y | theta] of every rank in one piece
-            e.resample_gather()
-        best = int(0xFFFFFFFF - (int(b.stats[0].item()) & 0xFFFFFFFF)) if self.want_best else -1
-        self._last = {"best": best, "resampled": did, "neff": neff, "kd_size": e.kd_size}
+        e.shard_weights()                       # global min / max / argmax, weights, pose = best + ICP increment; map lists start
+        p_w = self._all_gather(b.gw, b.w, async_op=True)   # the weights are final: gathered under the map update
+        for p in (p_pose, p_w):
+            if p is not None:
+                p.wait()                        # stream-level: orders the compute stream behind the collective
+        e.shard_finish()                        # Neff on the global weights, insert + header, gated resample, booking

@@ -28,8 +28,8 @@
  *   pfslam_traverse                    findCorrespondenceIndexKD          kernel.cu:924-972
  *   pfslam_topology_update, find_walls,
  *   check_loop_closure, get_topology   UpdateTopology / FindWalls / CheckLoopClosure   kernel.cu:623-795
- *   pfslam_shard_begin / weights / map / finish   particleFilter split where a multi-GPU caller merges shards (no reference
- *                                      counterpart: the reference is single-GPU)
+ *   pfslam_shard_disperse / score / weights / finish   particleFilter split where a multi-GPU caller places its three
+ *                                      all-gathers (no reference counterpart: the reference is single-GPU)
  */
 #ifndef PFSLAM_H
 #define PFSLAM_H
@@ -141,9 +141,10 @@ int pfslam_measurement_update(pfslam_handle *h, int *best, float *fmin, float *f
 int pfslam_icp(pfslam_handle *h, const float start[3], float pose_out[3], float *dbg29);
 int pfslam_update_map_kd(pfslam_handle *h);
 int pfslam_resample(pfslam_handle *h, int frame, int *resampled, float *neff);
-/* the two halves of pfslam_resample, for sharded handles: plan = Neff + cdf + source indices on the GLOBAL weights
- * (device buffer 10, filled by the caller's all-gather); gather = pull the chosen particles out of the GLOBAL pose
- * blocks (device buffer 17, all-gathered by the caller from buffer 16 when plan reports resampled = 1) */
+/* the two halves of pfslam_resample for callers that drive the STAGES of a sharded handle themselves (the sharded frame
+ * pfslam_shard_* needs neither): plan = Neff + cdf + source indices on the GLOBAL weights (device buffer 10, filled by the
+ * caller's all-gather); gather = pull the chosen particles out of the GLOBAL pose blocks (device buffer 17, all-gathered by the
+ * caller from buffer 16 when plan reports resampled = 1) */
 int pfslam_resample_plan(pfslam_handle *h, int frame, int *resampled, float *neff);
 int pfslam_resample_gather(pfslam_handle *h);
 int pfslam_score_grid(pfslam_handle *h, int32_t *fit_host);
@@ -182,25 +183,34 @@ int pfslam_maybe_balance(pfslam_handle *h, int frame);
 int pfslam_kd_size(pfslam_handle *h);
 
 /* ---- multi-GPU (particles sharded over ranks; the collectives are the caller's, e.g. RCCL over xGMI) ----
- * The sharded frame; the caller's collectives run between the calls on the handle's stream, ONE host sync per frame:
- *   pfslam_shard_begin      scan upload, re-balance if due, dispersion, score -> this rank's 32-byte record in buffer 14:
- *                           {int64 max key, int64 negated-min key, float x, y, theta, 0} of the shard's best particle;
- *                           key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index).  *seeded = 1 when the frame only
+ * The sharded frame.  Like pfslam_step it is only ENQUEUED: no call waits for the device, the frame is booked one step later
+ * from its pinned header, and the schedule of the caller's collectives is FIXED -- three all-gathers in every frame, none of
+ * them data-dependent (the resample is decided on the device, on the gathered weights, and reads its sources from the gathered
+ * pose blocks):
+ *   pfslam_shard_disperse   scan upload, re-balance if due, ICP fork, dispersion of this shard.  *seeded = 1 when the frame only
  *                           seeded the map (first scan): nothing else to do for this frame.
- *   [all-gather buffer 14 -> buffer 15]                        32 bytes per rank
+ *   [all-gather buffer 16 -> buffer 17]   pose blocks [x | y | theta] in ONE piece of 3 * shard_stride floats per rank.  They are
+ *                           final right after the dispersion, so the caller issues this on a SIDE stream (ordered behind the
+ *                           handle's stream by an event) and it runs UNDER the score kernel
+ *   pfslam_shard_score      lane order, plan, scan-match, reduce -> this rank's 32-byte record in buffer 14:
+ *                           {int64 max key, int64 negated-min key, float x, y, theta, 0} of the shard's best particle;
+ *                           key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index)
+ *   [all-gather buffer 14 -> buffer 15]   32 bytes per rank, on the handle's stream
  *   pfslam_shard_weights    global min / max / first argmax from the gathered records, weight update of this shard, pose =
- *                           best particle + increment of the ICP solve (which ran under the score kernel)
- *   [all-gather buffer 5 -> buffer 10]                         weights, shard_stride floats per rank; may overlap with ...
- *   pfslam_shard_map        ... the replicated map update's device chain (optional call; shard_finish runs it otherwise)
- *   pfslam_shard_finish     Neff on the gathered weights, frame header, the one host wait; resample plan when Neff < 0.7 N
- *                           (the new walls were inserted on the device by pfslam_shard_map)
- *   [all-gather buffer 16 -> buffer 17]  pfslam_resample_gather   only when *resampled: [x | y | theta] in ONE piece of
- *                                                                3 * shard_stride floats per rank
- * i.e. two collectives per frame, three in frames that resample.  Results are bit-identical for any number of ranks. */
-int pfslam_shard_begin(pfslam_handle *h, int frame, const float *scan_host, int *seeded);
+ *                           best particle + increment of the ICP solve (which ran under the score kernel); the replicated map
+ *                           update's rays, cell lists and list traversal start on the handle's aux stream
+ *   [all-gather buffer 5 -> buffer 10]    weights, shard_stride floats per rank, side stream, under the map update
+ *   pfslam_shard_finish     the caller first makes the handle's stream wait for BOTH side-stream all-gathers (event waits, no host
+ *                           wait); then: sums + Neff on the gathered weights, insert of the new walls + frame header, gated
+ *                           resample (sources from buffer 17), booking of the frame `lag` steps back
+ * Results are bit-identical for any number of ranks.  Buffer 16 alternates between two allocations with every frame (the resample
+ * kernel always moves the particles to the other block): query it after pfslam_shard_disperse of the same frame.
+ * A handle that holds ALL particles (global_n == n_particles) may be driven through the same calls (world 1): buffers 10 / 17
+ * then alias 5 / 16 and the all-gathers of weights and pose blocks are no-ops for the caller to skip. */
+int pfslam_shard_disperse(pfslam_handle *h, int frame, const float *scan_host, int *seeded);
+int pfslam_shard_score(pfslam_handle *h);
 int pfslam_shard_weights(pfslam_handle *h);
-int pfslam_shard_map(pfslam_handle *h);
-int pfslam_shard_finish(pfslam_handle *h, int frame, int *resampled, float *neff);
+int pfslam_shard_finish(pfslam_handle *h);
 /* stage-level merge hooks (the sharded frame above does not need them): local packed keys into the stats buffer 0
  * ([0] max key, [1] negated-min key: MAX-reduce across ranks), then weights + this rank's share of the best pose in buffer 8
  * (zero on non-owners: SUM-reduce across ranks) */
@@ -236,6 +246,13 @@ int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[12]);
 int pfslam_score_census(pfslam_handle *h, unsigned long long out[8]);
+/* census log: while enabled, every scoring pass of pfslam_step / pfslam_shard_score / pfslam_score_kd is followed by the counting
+ * instantiation of the scan-match kernel on the very SAME inputs (particles, scan, map, lane order, plan) -- one record of eight
+ * counters (the layout of pfslam_score_census) per pass, up to 1024 passes.  bench.py replays its timed frames on a second
+ * handle with the log on: the frame loop is deterministic, so the replay's launches are the timed launches.
+ * pfslam_get_census_log: *n = passes logged, out[k * 8 + c] for k < min(*n, cap). */
+int pfslam_set_census(pfslam_handle *h, int enable);
+int pfslam_get_census_log(pfslam_handle *h, unsigned long long *out, int cap, int *n);
 /* the chip's wave-level 16-byte gather rate measured live by a micro-benchmark (cache-resident 2 MB table, 8 waves per SIMD):
  * out[0] = wave gathers per second (whole chip), out[1] = compute units, out[2] = nominal clock in GHz, out[3] = cycles per
  * wave gather per CU at the nominal clock.  The scan-match kernel issues one such gather per node visit of a wave. */

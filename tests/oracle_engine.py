@@ -150,25 +150,31 @@ class OracleShardEngine:
         self.wm[sel] = self.w[sel]
         return best, float(fmin), float(fmax)
 
-    def shard_begin(self, frame, scan):
-        """pfslam_shard_begin: scan, re-balance if due, (first scan: seed the map), dispersion, score, this rank's record."""
+    def shard_disperse(self, frame, scan):
+        """pfslam_shard_disperse: scan, re-balance if due, (first scan: seed the map), ICP solve, dispersion."""
         self.set_scan(scan)
         self.maybe_balance(frame)
+        self.frame = frame
+        self._trace = {"best": -1, "resampled": 0, "kd_size": self.size}
         if self.size == 0:
             self.set_pose(np.zeros(3, np.float32))
             self.update_map_kd()
+            self._trace["kd_size"] = self.size
             return True
         # the replicated ICP solve depends on the scan, the previous pose and the map only (kernel.cu:984-990, 1081-1092)
         zero = np.zeros(3, np.float32)
         inc, _ = O.icp(self.tree, self.robot, zero, self.scan)
         self.icp_delta = inc.copy()
         self.motion_update(frame)
+        return False
+
+    def shard_score(self):
+        """pfslam_shard_score: scan-match of this shard, its packed min / max keys and the pose of its best particle."""
         self.score_kd(fetch=False)
         self.measurement_local()
         lb = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF)) - self.goff
         self.pack[0], self.pack[1] = self.stats[0], self.stats[1]
         self.pack[2:].view(np.float32)[:] = (self.x[lb], self.y[lb], self.th[lb], 0.0)
-        return False
 
     def shard_weights(self):
         """pfslam_shard_weights: merge the gathered records, weights, pose = best particle + ICP increment."""
@@ -176,16 +182,21 @@ class OracleShardEngine:
         owner = int(np.argmax(rec[:, 0]))            # first occurrence of the maximum key
         self.stats[0], self.stats[1] = rec[owner, 0], rec[:, 1].max()
         self.start[:] = rec[owner, 2:].copy().view(np.float32)
-        self._apply_weights()
+        best, _, _ = self._apply_weights()
+        self._trace["best"] = best
         self.robot[:] = self.start[:3] + self.icp_delta
 
-    def shard_map(self):
-        """pfslam_shard_map: the replicated map update at the ICP pose."""
+    def shard_finish(self):
+        """pfslam_shard_finish: the replicated map update at the ICP pose, Neff on the gathered weights, and -- decided
+        from Neff alone -- the resample out of the pose blocks gathered right after the dispersion."""
         self.update_map_kd()
+        did, neff = self.resample_plan(self.frame)
+        if did:
+            self.resample_gather()
+        self._trace.update(resampled=did, neff=neff, kd_size=self.size)
 
-    def shard_finish(self, frame):
-        """pfslam_shard_finish: Neff / resample plan on the gathered weights."""
-        return self.resample_plan(frame)
+    def trace(self):
+        return dict(self._trace)
 
     def resample_plan(self, frame):
         L = O.lib()

@@ -27,17 +27,24 @@ def test_bench_json_line_has_contract_fields():
     # the kernel is bound by the CU's gather path, not by HBM or MFMA: the block says so and every fraction in it is <= 1
     assert r["bound"] == "l1_gather" and r["unit"] == "GB/s" and r["launches"] == 3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] <= 1.02, r["frac"]
-    g = r["gathers"]
+    assert 0.0 < r["frac_of_nominal_peak"] <= 1.02 and r["peak_nominal"] > 0
+    g = r["census"]
+    # the gathers are counted on the timed launches themselves: a replay of the same frames, bit-identical state
+    assert g["launches"] == 3 and g["replay_identical"] is True
     assert g["wave_gathers_16B_per_launch"] > 0 and 1.0 <= g["lanes_active_per_trip"] <= 64.0
+    b = g["gather_bytes_per_launch"]
+    assert 0 < b["min"] <= b["mean"] <= b["max"]
+    assert abs(r["achieved"] - b["mean"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
     assert r["ubench"]["wave_gathers_per_s"] > 1e9 and r["ubench"]["cus"] >= 1
-    assert r["hbm"] is None or 0.0 <= r["hbm"]["frac"] <= 1.0     # no committed PMC summary for this small test workload
-    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["pmc"] is None                                       # no committed PMC summary for this small test workload
+    assert r["traffic"] is None
     assert r["alg_equiv"]["bytes_per_eval"] > 20
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and 1 <= c["cores"] <= c["logical_cpus"] and c["value"] > 0 and "sample" in c
     assert c["cpu_model"] and c["single_thread_value"] > 0
     lr = d["long_run"]
     assert lr["frames"] == 100 and lr["first_frame"] % 100 == 6 and lr["value"] > 0
+    assert d["value_long_run"] == lr["value"] and list(d)[:3] == ["metric", "value", "value_long_run"]
     ph = d["phases_ms"]
     assert all(ph[k] >= 0 for k in ("motion", "measurement", "map", "resample")) and ph["measurement"] > ph["motion"]
     assert abs(d["value"] - 5000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
@@ -67,3 +74,38 @@ def test_bench_under_torchrun_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["particles_global"] == 8192 and d["scaling"] == "weak"
     assert abs(d["value"] - 8192 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
     assert d["roofline"]["launches"] == 3 and "cpu_baseline" not in d
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun: bench.py starts the two ranks itself (gloo, both on GPU 0) and rank 0's
+    line is the only one printed."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--particles", "4096",
+           "--map-points", "20000", "--backend", "gloo", "--same-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600, env=env).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["particles_global"] == 8192 and d["roofline"]["launches"] == 3
+    assert d["roofline"]["census"]["replay_identical"] is True
+
+
+def test_roofline_census_agrees_with_committed_pmc():
+    """The default workload's census (counted by the replay inside bench.py) against the newest matching rocprofv3 summary under
+    profiles/: TA_BUFFER_READ_WAVEFRONTS_sum per launch is the counter's view of the same wave gathers.  A reader must be able to
+    recompute `frac` from that file alone."""
+    import glob
+    if not glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_pmc_score_kd.json")):
+        pytest.skip("no round-3+ PMC summary of the default workload committed yet")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"], cwd=ROOT, timeout=900).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    r = d["roofline"]
+    assert r["census"]["replay_identical"] is True and r["launches"] == 20
+    p = r["pmc"]
+    assert p is not None and p["ta_buffer_read_wavefronts_per_launch"], "profiles/ has no matching PMC summary with the TA counters"
+    assert abs(p["census_over_pmc_wavefronts"] - 1.0) < 0.10, p
+    # recompute frac from the PMC file alone: every wave gather priced as a 16-byte one (the counter cannot tell the 4-byte
+    # parent-index gathers apart: ~6 % of the gathers, so ~5 % too many bytes) / the timed launches' duration in the trace pass
+    pm = json.load(open(os.path.join(ROOT, p["source"])))
+    frac_pmc = pm["avg_per_launch"]["TA_BUFFER_READ_WAVEFRONTS_sum"] * 1024.0 / (pm["kernel_ms"] * 1e-3) / 1e9 / r["peak"]
+    assert abs(frac_pmc / r["frac"] - 1.0) < 0.12, (frac_pmc, r["frac"])

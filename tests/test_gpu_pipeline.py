@@ -115,3 +115,27 @@ def test_scans_of_2000_beams_insert_through_a_large_lds_window(pkg):
     assert inserted > 200
     assert h.map().tobytes() == o.tree().tobytes()
     h.close(); o.close()
+
+
+def test_kd_and_grid_frames_alternate_without_settling(pkg):
+    """pfslam_step leaves its map update running on the aux stream; a pfslam_step_grid right behind it uses the same masks,
+    pose, counts and sums (the host layer's particleFilterPC switches between the two loops).  No getter in between: the
+    frames stay in flight.  Trees, grid, particles and poses must equal the oracle's, which runs the same alternation."""
+    assert pkg.device_count() > 0
+    n, nframes = 3000, 26
+    segs, frames = pkg.synth.corridor_sequence(nframes, seed=11)
+    o = O.Slam(n, kd_capacity=1 << 16)
+    h = pkg.PfSlam(n, kd_capacity=1 << 16)
+    for f, (_, scan) in enumerate(frames, start=1):
+        grid_frame = f > 2 and f % 3 != 0           # KD, KD, then two grid frames after every KD frame
+        (o.step_grid if grid_frame else o.step)(f, scan)
+        (h.step_grid if grid_frame else h.step)(f, scan)
+        if f % 9 == 0:                              # an occasional look: books the frames in flight
+            assert (bits(h.pose) == bits(o.pose)).all(), f
+    assert (bits(h.pose) == bits(o.pose)).all()
+    assert h.map().tobytes() == o.tree().tobytes()
+    assert (h.grid() == o.grid).all()
+    got, want = h.particles(), o.particles()
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[fld]) == bits(want[fld])).all(), fld
+    h.close(); o.close()

@@ -17,8 +17,9 @@ def bits(a):
 
 @pytest.mark.parametrize("n_global,world", [(1000, 2), (1001, 3)])
 def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
-    """The sharded frame of include/pfslam.h with the all-gathers done by hand between handles that share one GPU: equal
-    shards (2 x 500) and a ragged job (1001 = 334 + 334 + 333, exchange buffers padded to the stride)."""
+    """The sharded frame of include/pfslam.h (fixed schedule: pose blocks, records, weights) with the all-gathers done by hand
+    between handles that share one GPU: equal shards (2 x 500) and a ragged job (1001 = 334 + 334 + 333, exchange buffers padded
+    to the stride)."""
     torch = pytest.importorskip("torch")
     assert pkg.device_count() > 0 and torch.cuda.is_available()
     sharded = importlib.import_module("gpu-icp-slam_amd.sharded")
@@ -37,10 +38,18 @@ def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
 
     for f, (pose, scan) in enumerate(frames, start=1):
         o.step(f, scan)
-        seeded = [e.shard_begin(f, scan) for e in engs]
+        seeded = [e.shard_disperse(f, scan) for e in engs]
         assert len(set(seeded)) == 1
         if seeded[0]:
             continue
+        sync()
+        blocks = [b.pose_blocks() for b in bufs]                                # the local block alternates: ask every frame
+        g = torch.cat([loc for loc, _ in blocks])                               # all-gather of the [x | y | theta] blocks
+        for _, glob in blocks:
+            glob.copy_(g)
+        sync()
+        for e in engs:
+            e.shard_score()
         sync()
         packs = torch.cat([b.pack for b in bufs])                               # all-gather of the 32-byte records
         for b in bufs:
@@ -54,22 +63,12 @@ def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
             b.gw.copy_(gw)
         sync()
         for e in engs:
-            e.shard_map()
-        plans = [e.shard_finish(f) for e in engs]
-        assert len(set(plans)) == 1
-        if plans[0][0]:
-            n_resampled += 1
-            blocks = [b.pose_blocks() for b in bufs]
-            g = torch.cat([loc for loc, _ in blocks])                           # all-gather of the [x | y | theta] blocks
-            for _, glob in blocks:
-                glob.copy_(g)
-            sync()
-            for e in engs:
-                e.resample_gather()
+            e.shard_finish()
         t = o.trace()
-        assert plans[0][0] == t["resampled"]
-        for e in engs:
-            assert e.trace()["best"] == t["best"]
+        n_resampled += t["resampled"]
+        for e in engs:                                                          # trace() books the frame in flight
+            te = e.trace()
+            assert te["best"] == t["best"] and te["resampled"] == t["resampled"]
             assert (bits(e.pose) == bits(o.pose)).all()
             assert e.kd_size == o.kd_size
     assert n_resampled > 0

@@ -40,10 +40,9 @@ def _worker(rank, world, port, n_global, n_frames, strict, out_dir):
         s.step(f, scan)
         t = s.trace()
         log.append((t.get("best", -1), t.get("resampled", 0), t.get("kd_size", 0)) + tuple(eng.robot.view(np.int32).tolist()))
-    # the fused protocol: two all-gathers per frame, a third one only in frames that resample
+    # the fixed schedule: three all-gathers in every frame (pose blocks, records, weights), whether it resamples or not
     n_stepped = sum(1 for row in log if row[0] >= 0)
-    n_resampled = sum(row[1] for row in log)
-    assert s.collectives == 2 * n_stepped + n_resampled, (s.collectives, n_stepped, n_resampled)
+    assert s.collectives == 3 * n_stepped, (s.collectives, n_stepped)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=eng.x, y=eng.y, th=eng.th, w=eng.w, log=np.array(log, np.int64),
              tree=eng.tree[:eng.size])
     dist.barrier()

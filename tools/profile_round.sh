@@ -32,7 +32,7 @@ for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True):
     with open(out + "/summary/kernel_stats.csv", "w") as g:
         w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
 # per-dispatch durations of the score kernel; the census launches (k_score_kd<..., true>) are a different instantiation
-timed_ms = None
+timed_ms = all_ms = None
 for f in glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if "k_score_kd" in r["Kernel_Name"]]
     plain = [r for r in rows if not re.search(r"(<|,\s*)true\s*>", r["Kernel_Name"])]   # the counting instantiations end in <..., true>
@@ -40,24 +40,50 @@ for f in glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True):
     durs = [x[1] / 1e3 for x in d]
     timed = durs[workload["warmup"]:workload["warmup"] + workload["steps"]]
     timed_ms = sum(timed) / max(len(timed), 1) / 1e3
+    all_ms = sum(durs) / max(len(durs), 1) / 1e3
     json.dump({"kernel": "k_score_kd", "workload": workload, "launch_us": durs, "mean_us_all": sum(durs) / len(durs),
                "mean_us_timed": timed_ms * 1e3,
-               "note": "first %d launches are bench.py's untimed warm-up steps; mean_us_timed = the %d timed ones" % (workload["warmup"], workload["steps"])},
+               "note": "first %d launches are bench.py's untimed warm-up steps; mean_us_timed = the %d timed ones; the launches behind "
+                       "them are bench.py's census replay of the same %d frames (same states, so the same durations) and, without "
+                       "--no-cpu-baseline, the long-run leg" % (workload["warmup"], workload["steps"], workload["warmup"] + workload["steps"])},
               open(out + "/summary/score_kd_launches.json", "w"), indent=1)
-# PMC per launch of the score kernel (timed instantiation only)
-pm = collections.defaultdict(list)
+# PMC per launch of the scan-match kernel: the timed instantiation only, and of its launches only bench.py's TIMED ones --
+# dispatches [warmup, warmup + steps) of the process (the warm-up launches before them score a younger map; the launches behind
+# them belong to bench.py's census replay of the same frames) -- so that the averages describe exactly the launches the JSON
+# line's roofline block is about
+pm, pm_all, dur = collections.defaultdict(list), collections.defaultdict(list), {}
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "k_score_kd" in k and not re.search(r"(<|,\s*)true\s*>", k):
-            pm[r["Counter_Name"]].append(float(r["Counter_Value"]))
-avg = {k: sum(v) / len(v) for k, v in pm.items()}
-res = {"kernel": "k_score_kd", "workload": workload, "kernel_ms": timed_ms, "launches_profiled": {k: len(v) for k, v in pm.items()}, "avg_per_launch": avg}
+            per[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for name, rows in per.items():
+        rows.sort()
+        # one row per (dispatch, counter instance): sum the instances of a dispatch
+        by = collections.OrderedDict()
+        for d, v, t in rows:
+            by.setdefault(d, [0.0, t])[0] += v
+        vals = list(by.values())
+        timed = vals[workload["warmup"]:workload["warmup"] + workload["steps"]]
+        pm[name] = [v for v, _ in timed]
+        pm_all[name] = [v for v, _ in vals]
+        dur[name] = sum(t for _, t in timed) / max(len(timed), 1) / 1e6   # ms, in THAT pass (counters perturb durations)
+avg = {k: sum(v) / len(v) for k, v in pm.items() if v}
+res = {"kernel": "k_score_kd", "workload": workload, "kernel_ms": timed_ms, "kernel_ms_all": all_ms,
+       "launches_profiled": {k: len(v) for k, v in pm.items()}, "avg_per_launch": avg,
+       "avg_per_launch_all_launches": {k: sum(v) / len(v) for k, v in pm_all.items() if v},
+       "pass_kernel_ms": dur}
+if "GRBM_GUI_ACTIVE" in avg and dur.get("GRBM_GUI_ACTIVE"):
+    res["measured_clock_ghz"] = avg["GRBM_GUI_ACTIVE"] / 8.0 / (dur["GRBM_GUI_ACTIVE"] * 1e-3) / 1e9   # the counter sums the 8 XCDs
 if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 rocprofv3 reports half the bytes of wide reads (MI355X_MICROARCH.md, HBM)
     res["hbm_bytes_per_launch"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
     res["hbm_bytes_note"] = "(2 x FETCH_SIZE + WRITE_SIZE) KB; the x2 read correction is the guide's and is uncalibrated for 16-B gathers, so this is an upper bound"
-res["kernel_ms_note"] = "mean duration of the timed launches in the --kernel-trace pass of the same command (PMC passes perturb durations)"
+res["kernel_ms_note"] = ("kernel_ms = mean duration of the TIMED launches (dispatches [warmup, warmup + steps) of the timed instantiation) in the "
+                         "--kernel-trace pass of the same command; avg_per_launch = the same launches in the PMC passes; pass_kernel_ms = "
+                         "their mean duration inside each PMC pass (counters perturb durations: use it only with counters of that pass, "
+                         "e.g. measured_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / pass duration)")
 json.dump(res, open(out + "/summary/pmc_score_kd.json", "w"), indent=1)
 print(json.dumps(res)[:800])
 PY

@@ -432,6 +432,9 @@ def main():
             "bound": "l1_gather", "achieved": achieved, "peak": peak_measured, "unit": "GB/s", "frac": achieved / peak_measured,
             "traffic": traffic,
             "frac_of_nominal_peak": achieved / peak_nominal,
+            # every wave gather priced as a full 16-byte one (a hardware counter cannot tell the 4-byte parent-index gathers apart):
+            # the figure a reader recomputes from profiles/ alone as TA_BUFFER_READ_WAVEFRONTS_sum x 1024 B / kernel_ms / peak
+            "frac_all_gathers_as_16B": (g16 + g4) * 1024.0 / kern_s / 1e9 / peak_measured,
             "peak_nominal": peak_nominal, "peak_nominal_clock_ghz": ghz,
             "peak_nominal_clock_source": ("GRBM_GUI_ACTIVE / 8 / kernel time of " + os.path.relpath(pmc_path, ROOT)) if clock_ghz else "nominal clock (hipDeviceProp)",
             "kernel": "k_score_kd_plan" if plan_stats["rows"] else "k_score_kd", "kernel_ms": kern_s * 1e3, "launches": launches,

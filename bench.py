@@ -394,6 +394,7 @@ def main():
         kern_s = max(timers["score_ms"] / launches, 1e-9) * 1e-3
         plan_ms = timers["plan_ms"] / max(timers["plan_count"], 1)
         plan_stats = e0.plan_stats()
+        cell_stats = e0.cell_stats()
         ub = e0.ubench_gather()
         # wave-level gathers per launch, from the replay's census of the SAME launches.  A descent-loop trip is one 16-byte wave
         # gather; a parent-hyperplane test one 16-byte + one 4-byte wave gather.  Bytes are lane-level: 64 lanes x record size.
@@ -437,7 +438,8 @@ def main():
             "frac_all_gathers_as_16B": (g16 + g4) * 1024.0 / kern_s / 1e9 / peak_measured,
             "peak_nominal": peak_nominal, "peak_nominal_clock_ghz": ghz,
             "peak_nominal_clock_source": ("GRBM_GUI_ACTIVE / 8 / kernel time of " + os.path.relpath(pmc_path, ROOT)) if clock_ghz else "nominal clock (hipDeviceProp)",
-            "kernel": "k_score_kd_plan" if plan_stats["rows"] else "k_score_kd", "kernel_ms": kern_s * 1e3, "launches": launches,
+            "kernel": "k_score_kd_cells" if cell_stats["rows"] else "k_score_kd_plan" if plan_stats["rows"] else "k_score_kd",
+            "kernel_ms": kern_s * 1e3, "launches": launches,
             "kernel_evals_per_s": n_local / kern_s,
             "census": {"launches": len(cen_timed), "replay_identical": replay_identical,
                        "gather_bytes_per_launch": {"min": float(min(gbytes)), "mean": gather_bytes, "max": float(max(gbytes))},
@@ -450,7 +452,12 @@ def main():
                                "`replay_identical`) with the counting instantiation of the kernel behind every scoring pass; "
                                "wave_gathers_per_launch = trips + 2 x tests = what TA_BUFFER_READ_WAVEFRONTS_sum counts for the same "
                                "launches (pmc.census_over_pmc_wavefronts)" % (FIRST_FRAME, FIRST_FRAME + a.warmup + a.steps - 1)},
-            "plan": dict(plan_stats, kernel_ms=plan_ms,
+            "cells": dict(cell_stats, kernel_ms=plan_ms,
+                          note="lattice-cell rows of the LAST timed launch (pfslam_cell_stats, csrc/kd_cells.hip.inc): cells under the waves' "
+                               "beam-end boxes, one row per cell = the few nodes of the cell's first descent that can be nearest for some "
+                               "query of the cell (+ re-descent candidates); kernel_ms = k_group_box + k_cells_mark + k_cell_rows, which "
+                               "run before the scan-match kernel") if cell_stats["rows"] else None,
+            "plan": None if cell_stats["rows"] else dict(plan_stats, kernel_ms=plan_ms,
                          note="shared-prefix plan of the LAST timed launch (pfslam_plan_stats): one planning lane per (wave, beam) walks "
                               "the root path common to the wave's 64 queries and keeps only the nodes that can be nearest for some "
                               "lane; kernel_ms = k_group_box + k_plan, which run before the scan-match kernel"),

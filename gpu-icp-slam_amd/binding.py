@@ -24,7 +24,7 @@ SYMBOLS = [
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats",
 ]
 
 
@@ -127,6 +127,7 @@ def load():
     L.pfslam_get_census_log.argtypes = [vp, vp, i32, vp]
     L.pfslam_ubench_gather.argtypes = [vp, vp]
     L.pfslam_plan_stats.argtypes = [vp, vp]
+    L.pfslam_cell_stats.argtypes = [vp, vp]
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -376,6 +377,13 @@ class PfSlam:
         out = (C.c_double * 10)()
         _chk(self.L.pfslam_plan_stats(self._h, out), "pfslam_plan_stats")
         keys = ("rows", "path_len", "candidates", "frac_complete", "frac_no_plan", "frac_full", "box_dx", "box_dy", "box_dtheta", "waves")
+        return dict(zip(keys, [float(v) for v in out]))
+
+    def cell_stats(self):
+        """Lattice-cell rows of the last scoring pass (all zero when it did not use them)."""
+        out = (C.c_double * 8)()
+        _chk(self.L.pfslam_cell_stats(self._h, out), "pfslam_cell_stats")
+        keys = ("cells", "rows", "candidates", "redescent_candidates", "cells_without_row", "pool_slots", "window_kx", "window_ky")
         return dict(zip(keys, [float(v) for v in out]))
 
     def ubench_gather(self):

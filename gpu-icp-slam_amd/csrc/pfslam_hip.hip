@@ -189,6 +189,12 @@ struct pfslam_handle {
     size_t plan_rows = 0;
     bool plan_valid = false; // the last scoring pass made a plan
     pf::KdGroupBox *group_box = nullptr;
+    // lattice-cell rows (kd_cells.hip.inc)
+    bool lattice_ok = false;   // planar map, every node on the lattice k * res of the config (all maps the SLAM step builds are)
+    bool cells_valid = false;  // the last scoring pass used cell rows
+    unsigned *cell_tab = nullptr;
+    int *cell_list = nullptr, *cell_state = nullptr;
+    uint4 *cell_pool = nullptr;
 };
 
 // ==========================================================================================
@@ -253,7 +259,9 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
 }
 
-// ---- shared-prefix plan (kd_device.h "Shared-prefix plan") ------------------------------------------------------
+#include "kd_cells.hip.inc" // round 3: lattice-cell rows (k_cells_mark, k_cell_rows, k_score_kd_cells); beam_box is shared with k_plan
+
+// ---- shared-prefix plan (kd_device.h "Shared-prefix plan"): round 2; still used for planar maps that are not on the lattice -----
 // pose bounding box of every group of 64 lanes (= one wave of the score kernel)
 __global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, const float *__restrict__ py, const float *__restrict__ pth,
                                                   int n, const int *__restrict__ order, pf::KdGroupBox *__restrict__ box)
@@ -293,25 +301,13 @@ __global__ __launch_bounds__(64) void k_plan(const pf::KdGroupBox *__restrict__ 
     pf::KdPlanRow *row = plan + ((size_t)g * nb + j);
     const pf::KdGroupBox b = box[g];
     const float r = scan[j];
-    const float tc = 0.5f * (b.tlo + b.thi), dth = 0.5f * (b.thi - b.tlo);
-    // egocentric end point at the centre heading (the lanes' own formula).  d/dphi of (r cos phi, r sin phi) is
-    // (-r sin phi, r cos phi), and |sin|, |cos| are 1-Lipschitz: over the group's headings the end point moves by at most
-    // (|cy| + |r| d) d in x and (|cx| + |r| d) d in y; eps covers the lanes' float rounding and the 1-ulp sincos many times over
-    float cx, cy;
-    pf::clean_lidar_scan(j, r, tc, cx, cy);
-    // ... and the rounding of rot = angle + theta itself, which grows with |theta| (headings are never normalised): the centre and
-    // every lane each round their own sum to 0.5 ulp(|rot|) <= 2^-24 (|theta| + 2.36), i.e. up to |r| * 2 ulp of end-point motion
-    const float dd = dth + 1e-6f;
-    const float eps = 2e-4f + 1e-5f * fabsf(r) + fabsf(r) * 2.0f * 1.1920929e-7f * (fabsf(tc) + 2.4f + dd);
-    const float hx = (fabsf(cy) + fabsf(r) * dd) * dd + eps, hy = (fabsf(cx) + fabsf(r) * dd) * dd + eps;
-    const float wxlo = b.xlo + cx - hx, wxhi = b.xhi + cx + hx, wylo = b.ylo + cy - hy, wyhi = b.yhi + cy + hy;
+    float wxlo, wxhi, wylo, wyhi;
+    // no plan (every lane walks from the root): non-finite or absurd geometry, NaN poses, and beams no lane can accept
+    // (|r| >= PF_RANGE_NEVER puts |r cos| or |r sin| beyond the 20 m reject of kernel.cu:1213 for every heading: the score kernel
+    // skips such beams outright)
+    const bool usable = beam_box(b, j, r, wxlo, wxhi, wylo, wyhi);
     int n_cand = 0, resume = 0, path_len = 0;
     float U = INFINITY; // upper bound (with margin) of the final minimum for every point of W
-    // no plan (every lane walks from the root): non-finite or absurd geometry, NaN poses
-    // ... nor for a beam no lane can accept: |r| >= PF_RANGE_NEVER puts |r cos| or |r sin| beyond the 20 m reject of
-    // kernel.cu:1213 for every heading (max(|cos|, |sin|) >= 0.7071); the score kernel skips such beams outright
-    const bool usable = (wxlo == wxlo) && (wxhi == wxhi) && (wylo == wylo) && (wyhi == wyhi) && fabsf(wxlo) < 1e6f && fabsf(wxhi) < 1e6f &&
-                        fabsf(wylo) < 1e6f && fabsf(wyhi) < 1e6f && (wxhi - wxlo) < 4.0f && (wyhi - wylo) < 4.0f && fabsf(r) < PF_RANGE_NEVER;
     if (usable) {
         int head = 0;
         while (head >= 0) {
@@ -488,9 +484,11 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
 }
 // reach: metres per radian -- a heading difference d moves a beam end point by ~ reach * d, so one cell is equally wide in x, y
 // and reach * theta (what makes the 64 queries of a wave a small box, see the shared-prefix plan)
+// cs != nullptr (lattice-cell rows, kd_cells.hip.inc): block 0 also resets the pass's cell counters and puts the window of the
+// cell table around the cloud's mean
 __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x, const float *__restrict__ y,
                                                     const float *__restrict__ th, int n, float reach, int bits,
-                                                    unsigned *__restrict__ cell, int *__restrict__ hist)
+                                                    unsigned *__restrict__ cell, int *__restrict__ hist, int *__restrict__ cs, CellGeom geo)
 {
     __shared__ float red[4];
     const int ns = min(n, 1024); // cloud statistics, identical in every block
@@ -498,6 +496,12 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     for (int k = threadIdx.x; k < ns; k += 256) { sx += x[k]; sy += y[k]; st += th[k]; }
     const float inv = 1.0f / (float)ns;
     const float mx = block_sum_256(sx, red) * inv, my = block_sum_256(sy, red) * inv, mt = block_sum_256(st, red) * inv;
+    if (cs && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 8; k++) cs[k] = 0;
+        const bool fin = fabsf(mx) < 1e6f && fabsf(my) < 1e6f; // NaN poses among the first slots: any window will do
+        cs[2] = (fin ? lattice_floor(mx, geo.resx, geo.invx) : 0) - PF_CELL_WIN / 2;
+        cs[3] = (fin ? lattice_floor(my, geo.resy, geo.invy) : 0) - PF_CELL_WIN / 2;
+    }
     float vx = 0, vy = 0, vt = 0;
     for (int k = threadIdx.x; k < ns; k += 256) {
         const float a = x[k] - mx, b = y[k] - my, c = th[k] - mt;
@@ -739,6 +743,7 @@ static int create_impl(pfslam_handle *h)
     }
     HIPCHK(hipHostMalloc((void **)&h->h_scan, (size_t)PF_HDR_SLOTS * h->nb * 4));
     if (const char *e = getenv("PFSLAM_LAG")) h->lag = std::min(std::max(atoi(e), 0), PF_MAX_LAG);
+    if (const char *e = getenv("PFSLAM_VARIANT")) h->variant = atoi(e); // initial pfslam_set_variant (A/B runs, the fuzz)
     h->h_nodes.reserve(1024);
     // particleFilterInit (kernel.cu:122-132): grid = -100, particles at the origin with w = 1, robotPos = 0
     std::vector<float> ones(n, 1.0f);
@@ -826,6 +831,10 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->census_store) (void)hipFree(h->census_store);
     if (h->plan) (void)hipFree(h->plan);
     if (h->group_box) (void)hipFree(h->group_box);
+    if (h->cell_tab) (void)hipFree(h->cell_tab);
+    if (h->cell_list) (void)hipFree(h->cell_list);
+    if (h->cell_state) (void)hipFree(h->cell_state);
+    if (h->cell_pool) (void)hipFree(h->cell_pool);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -960,6 +969,18 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
         // |w| <= 2^13 keeps every partial sum of 1081 weights below 2^24, i.e. exact in any order
         if (!(nd.w == (float)(int)nd.w && fabsf(nd.w) <= 8192.0f)) integral = false;
     }
+    // on the lattice of the config?  x == fl(k * res) bit for bit, the way cell_to_point (ROUND_FRAC, kernel.cu:52) makes map points
+    bool lattice = planar != 0;
+    {
+        const float rx = h->cfg.map_res_x, ry = h->cfg.map_res_y, ix = 1.0f / rx, iy = 1.0f / ry;
+        for (int i = 0; i < n && lattice; i++) {
+            const pfslam_node &nd = nodes[i];
+            if (!(fabsf(nd.x) < 2e4f && fabsf(nd.y) < 2e4f)) { lattice = false; break; } // |k| < 2^20 at 2.5 cm; NaN fails
+            const float kx = roundf(nd.x * ix), ky = roundf(nd.y * iy);
+            lattice = (kx * rx == nd.x || (kx + 1.0f) * rx == nd.x || (kx - 1.0f) * rx == nd.x) &&
+                      (ky * ry == nd.y || (ky + 1.0f) * ry == nd.y || (ky - 1.0f) * ry == nd.y);
+        }
+    }
     for (int i = 0; i < n; i++) {
         const pfslam_node &nd = nodes[i];
         hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right, planar != 0);
@@ -978,6 +999,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     h->mirror_stale = false;
     h->planar = planar;
     h->integral_w = integral;
+    h->lattice_ok = lattice;
     return 0;
 }
 
@@ -1197,52 +1219,77 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         out = h->partial;
     }
     const int *order = nullptr;
+    // How the scoring pass is organised (results are bit-identical): variant 0 = default; 1 = identity lane order; 2 = plain per-lane
+    // traversal; 3 = plan / cell rows at any particle count; 4 = the round-2 shared-prefix plan instead of cell rows (A/B, tests).
+    // With few particles neither pays for its extra launches: measured break-even of the plan ~6 k particles (scoring pass at
+    // 5 k / 10 k / 50 k particles: 0.203 / 0.313 / 0.841 ms with the plan, 0.198 / 0.353 / 1.327 ms without).
+    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 6144;
+    const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
+    const bool use_cells = organised && h->lattice_ok && h->variant != 4; // lattice-cell rows (kd_cells.hip.inc)
+    const bool use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);
+    const CellGeom geo{h->cfg.map_res_x, h->cfg.map_res_y, 1.0f / h->cfg.map_res_x, 1.0f / h->cfg.map_res_y};
+    if (use_cells && !h->cell_tab) {
+        CHK(dalloc(&h->cell_tab, (size_t)PF_CELL_WIN * PF_CELL_WIN));
+        CHK(dalloc(&h->cell_list, (size_t)PF_CELL_LIST_CAP));
+        CHK(dalloc(&h->cell_state, 16));
+        CHK(dalloc(&h->cell_pool, (size_t)PF_CELL_POOL_CAP));
+        HIPCHK(hipMemsetAsync(h->cell_tab, 0, (size_t)PF_CELL_WIN * PF_CELL_WIN * 4, h->stream));
+        HIPCHK(hipMemsetAsync(h->cell_state, 0, 64, h->stream));
+    }
     // default: counting sort over Hilbert cells of the cloud (3 launches), 2^18 cells up to 400 k particles, 2^21 above
     static const float theta_weight = getenv("PFSLAM_THETA_WEIGHT") ? (float)atof(getenv("PFSLAM_THETA_WEIGHT")) : 1.0f;
     if (h->variant != 1 && h->n > 64) {
         const int bits = h->n <= 400000 ? 6 : PF_CELL_BITS_MAX, ncell = 1 << (3 * bits);
         int *hist = h->cells, *cursor = h->cells + ncell, *tile_tot = h->cells + 2 * ncell;
-        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan_reach * theta_weight, bits, h->mkey, hist);
+        hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan_reach * theta_weight, bits, h->mkey, hist,
+                           use_cells ? h->cell_state : (int *)nullptr, geo);
         hipLaunchKernelGGL(k_cell_scan, dim3(ncell / 1024), dim3(256), 0, h->stream, hist, cursor, tile_tot);
         hipLaunchKernelGGL(k_cell_scatter, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->mkey, h->n, cursor, tile_tot, ncell / 1024, h->order2);
         HIPCHK(hipGetLastError());
         order = h->order2;
     } // variant 1 = identity lane order
     const int direct = used > 1 ? 0 : 1;
-    // Shared-prefix plan (planar maps; variant 2 = off, the plain per-lane traversal; variant 3 = on at any size; for A/B and
-    // tests): pose box of every wave, then one planning lane per (wave, beam).  With few particles the 64 poses of a wave lie
-    // too far apart for the plan to pay for its two launches: measured break-even ~6 k particles (scoring pass at 5 k / 10 k /
-    // 50 k particles: 0.203 / 0.313 / 0.841 ms with the plan, 0.198 / 0.353 / 1.327 ms without).
-    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 6144;
-    const bool use_plan = h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant == 3);
     h->plan_valid = use_plan;
-    if (use_plan) { // the pose boxes do not need the map: in front of the join
+    h->cells_valid = use_cells;
+    if (use_plan || use_cells) { // the pose boxes do not need the map: in front of the join
         const int groups = (h->n + 63) / 64;
+        if (!h->group_box) CHK(dalloc(&h->group_box, (size_t)groups)); // n is fixed for the handle's lifetime
         const size_t rows = (size_t)groups * h->nb;
-        if (rows > h->plan_rows) {
+        if (use_plan && rows > h->plan_rows) {
             if (h->plan) HIPCHK(hipFree(h->plan));
-            if (h->group_box) HIPCHK(hipFree(h->group_box));
             h->plan = nullptr;
-            h->group_box = nullptr;
             CHK(dalloc(&h->plan, rows));
-            CHK(dalloc(&h->group_box, (size_t)groups));
             h->plan_rows = rows;
         }
         hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box);
     }
-    CHK(join_map(h)); // from here on the scoring pass reads the map (lane order and pose boxes above did not)
     hipEvent_t t_a = nullptr, t_b = nullptr;
     if (h->timing && !census) {
         CHK(timer_event(h, &t_a));
         CHK(timer_event(h, &t_b));
         HIPCHK(hipEventRecord(t_a, h->stream));
     }
+    if (use_cells) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
+        const int groups = (h->n + 63) / 64, per_block = PF_MARK_THREADS * PF_MARK_GROUPS;
+        hipLaunchKernelGGL(k_cells_mark, dim3(h->nb, (groups + per_block - 1) / per_block), dim3(PF_MARK_THREADS), 0, h->stream,
+                           (const pf::KdGroupBox *)h->group_box, groups, (const float *)h->scan, h->nb, geo, h->cell_tab, h->cell_list, h->cell_state);
+    }
+    CHK(join_map(h)); // from here on the scoring pass reads the map (lane order, pose boxes and cell marking above did not)
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
     // (2.387 vs 2.400 ms with 256-thread groups)
     const dim3 grid64((h->n + 63) / 64, used), grid256((h->n + 255) / 256, used);
     // the scan-match kernel itself; cen != nullptr: its counting instantiation (same launch shape, lane order, plan and results)
     auto scan_match = [&](pf::KdCensus *cen) {
-        if (use_plan) {
+        if (use_cells) {
+            if (cen)
+                hipLaunchKernelGGL((k_score_kd_cells<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                                   kd_view(h), geo, (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state,
+                                   order, direct, out, cen);
+            else
+                hipLaunchKernelGGL((k_score_kd_cells<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                                   kd_view(h), geo, (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state,
+                                   order, direct, out, (pf::KdCensus *)nullptr);
+        } else if (use_plan) {
             if (cen)
                 hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
                                    kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, cen);
@@ -1262,10 +1309,14 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
                                kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
     };
-    if (use_plan) {
+    if (use_plan || use_cells) {
         const int groups = (h->n + 63) / 64;
-        hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
-                           (const float *)h->scan, h->nb, kd_view(h), h->plan);
+        if (use_cells) { // one row per marked cell
+            hipLaunchKernelGGL(k_cell_rows, dim3(2048), dim3(64), 0, h->stream, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list,
+                               h->cell_state, h->cell_pool);
+        } else
+            hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
+                               (const float *)h->scan, h->nb, kd_view(h), h->plan);
         if (t_a) { // the planning launches are timed on their own: t_a .. t_p; t_p .. t_b brackets the scan-match kernel only
             hipEvent_t t_p = nullptr;
             CHK(timer_event(h, &t_p));
@@ -1283,6 +1334,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // census log (pfslam_set_census): the counting instantiation once more on the very same inputs, one record per scoring pass
     if (h->census_log && !census && h->census_n < PF_CENSUS_LOG) {
         scan_match(h->census_log + h->census_n++);
+        HIPCHK(hipGetLastError());
+    }
+    if (use_cells) { // wipe the pass's cells: the table is all zero between passes
+        hipLaunchKernelGGL(k_cells_clear, dim3(128), dim3(256), 0, h->stream, h->cell_tab, (const int *)h->cell_list, h->cell_state);
         HIPCHK(hipGetLastError());
     }
     if (fuse_minmax) {
@@ -1450,6 +1505,31 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
     for (int k = 0; k < 5; k++) out[1 + k] = v[k] / (double)rows;
     for (int k = 0; k < 3; k++) out[6 + k] = v[5 + k] / groups;
     out[9] = groups;
+    return 0;
+}
+
+// the lattice-cell rows of the LAST scoring pass: out[0] cells marked, [1] rows built, [2] mean first-descent candidates per row,
+// [3] mean re-descent candidates per row, [4] marked cells left without a row (too many candidates / pool exhausted: generic lanes),
+// [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell.  All zero when the pass did not use cell rows.
+extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[8])
+{
+    if (!h || !out) return fail("pfslam_cell_stats: bad argument");
+    for (int k = 0; k < 8; k++) out[k] = 0.0;
+    if (!h->cell_state || !h->cells_valid) return 0;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    int cs[16];
+    HIPCHK(hipMemcpyAsync(cs, h->cell_state, sizeof(cs), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int *last = cs + 8; // k_cells_clear's copy of the finished pass
+    out[0] = last[0];
+    out[1] = last[4];
+    out[2] = last[4] ? (double)last[5] / last[4] : 0.0;
+    out[3] = last[4] ? (double)last[6] / last[4] : 0.0;
+    out[4] = last[7];
+    out[5] = last[1];
+    out[6] = last[2];
+    out[7] = last[3];
     return 0;
 }
 

@@ -239,9 +239,10 @@ int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
  *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them, out[4] trips in which every
  *   active lane stood on the same node, out[5] those of them on the common path of all 64 lanes from the root.
  * pfslam_set_variant: how the scoring pass is organised (results are bit-identical; A/B measurements and tests): 0 = default
- *   (lanes along a Hilbert curve: counting sort over cells of the cloud; the shared-prefix plan from ~6 k particles),
- *   1 = identity lane order, 2 = no shared-prefix plan (every lane walks the whole traversal), 3 = the plan at any particle
- *   count. */
+ *   (lanes along a Hilbert curve: counting sort over cells of the cloud; from ~6 k particles on a planar map: lattice-cell rows
+ *   when every map point lies on the lattice k * resolution -- true of every map the SLAM step builds --, the round-2
+ *   shared-prefix plan otherwise), 1 = identity lane order, 2 = the plain per-lane traversal, 3 = cell rows / plan at any
+ *   particle count, 4 = like 3 but always the shared-prefix plan.  The environment variable PFSLAM_VARIANT sets the initial value. */
 int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_launch);
 int pfslam_set_timing(pfslam_handle *h, int enable);
 int pfslam_get_timers(pfslam_handle *h, double out[12]);
@@ -262,6 +263,10 @@ int pfslam_ubench_gather(pfslam_handle *h, double out[4]);
  * [4] fraction without a plan, [5] fraction with a full candidate list, [6..8] mean extent of a wave's pose box in x, y (m) and
  * heading (rad), [9] waves.  All zero when no plan was made (non-planar map, few particles, variant 2). */
 int pfslam_plan_stats(pfslam_handle *h, double out[10]);
+/* the lattice-cell rows of the LAST scoring pass (csrc/kd_cells.hip.inc): out[0] cells marked, [1] rows built, [2] mean
+ * first-descent candidates per row, [3] mean re-descent candidates per row, [4] marked cells left without a row, [5] 16-byte
+ * pool slots used, [6] [7] lattice index of the window's corner cell.  All zero when the pass did not use cell rows. */
+int pfslam_cell_stats(pfslam_handle *h, double out[8]);
 int pfslam_set_variant(pfslam_handle *h, int variant);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */

@@ -230,6 +230,8 @@ def test_differential_fuzz_of_the_frame_loop():
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     # and once more with the shared-prefix plan of the score kernel on at EVERY particle count (by default it starts at ~6 k
     # particles): tiny waves, partly filled waves, NaN / Inf scans and clouds at the map edge all go through the planning kernel
-    env = dict(os.environ, PFSLAM_PLAN_MIN_N="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_step.py"), "15", "11"], capture_output=True, text=True, timeout=300, env=env)
-    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # (lattice-cell rows -- the SLAM step's own maps lie on the lattice --, then the round-2 shared-prefix plan)
+    for extra, seed in (({}, "11"), ({"PFSLAM_VARIANT": "4"}, "12")):
+        env = dict(os.environ, PFSLAM_PLAN_MIN_N="1", **extra)
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_step.py"), "15", seed], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -195,14 +195,21 @@ def test_lane_order_variants_are_bit_identical(gpu, small_world, variant):
         # no-op re-descents) and the census says how many
         assert 0 < c["visits"] <= visits and c["trips"] * 64 >= c["visits"] and c["tests"] * 64 >= c["test_lanes"] > 0
         assert c["redescents_noop"] <= c["redescents"]
-        for v in (2, 3):   # 2 = the plain per-lane traversal (no plan), 3 = the shared-prefix plan forced on: same scores
+        # 2 = the plain per-lane traversal, 3 = lattice-cell rows forced on (the synthetic map lies on the lattice), 4 = the round-2
+        # shared-prefix plan forced on: same scores
+        for v in (2, 3, 4):
             h.set_variant(v)
-            assert (bits(h.score_kd()) == bits(want)).all()
-            stats = h.plan_stats()
-            assert (stats["rows"] > 0) == (v == 3)
-            if v == 3:
+            assert (bits(h.score_kd()) == bits(want)).all(), v
+            stats, cells = h.plan_stats(), h.cell_stats()
+            assert (stats["rows"] > 0) == (v == 4) and (cells["rows"] > 0) == (v == 3)
+            if v == 4:
                 # 3000 particles: wide wave boxes, many rows straddle early -- but there is a plan, and it prunes
                 assert stats["waves"] == (n + 63) // 64 and 0.0 < stats["candidates"] < stats["path_len"] and stats["path_len"] > 3
+            if v == 3:
+                # every marked cell got a row, a handful of candidates each
+                assert cells["cells"] >= cells["rows"] > 100 and 1.0 <= cells["candidates"] <= 12.0 and cells["cells_without_row"] < 0.01 * cells["cells"]
+                c3 = h.score_census()
+                assert c3["prefix_trips"] >= valid                                                # every in-range query found its row
         h.set_variant(variant)
         assert (bits(h.score_kd()) == bits(want)).all()
         h.close()

@@ -73,11 +73,20 @@ __device__ __forceinline__ int kd_load_i32(kd_rsrc_t r, int idx)
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, idx << 2, 0, 0);
 }
+// 16 bytes at byte offset `base` + `imm` (imm a compile-time constant: it goes into the instruction's offset field, so several
+// requests off one address cost no address arithmetic)
+__device__ __forceinline__ uint4 kd_load_hot_at(kd_rsrc_t r, int base, int imm)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, base + imm, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 #else // hipcc's host pass only parses the device templates below; the descriptor type does not exist there
 struct kd_rsrc_t { const void *base; };
 __device__ kd_rsrc_t kd_rsrc(const void *base);
 __device__ uint4 kd_load_hot(kd_rsrc_t r, int idx);
 __device__ int kd_load_i32(kd_rsrc_t r, int idx);
+__device__ uint4 kd_load_hot_at(kd_rsrc_t r, int base, int imm);
 #endif
 
 // Per-lane census counters (registers): a wave-level event is booked on its first active lane, every active lane books
@@ -272,14 +281,24 @@ static_assert(sizeof(KdPlanRow) == 16 + 16 * PF_PLAN_CAND, "plan row layout");
 struct KdGroupBox { float xlo, xhi, ylo, yhi, tlo, thi; int count, pad; }; // pose bounding box of a wave's 64 particles
 
 // LIDAR_ANGLE(i) (kernel.cu:42) + CleanLidarScan (kernel.cu:182-187)
-__device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)
+__device__ __forceinline__ float lidar_angle(int n)
 {
     const float PI_F = 3.1415926535897932384626422832795028841971f; // utilities.h:12
-    float rot = fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f) + theta;
+    return fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f);
+}
+// with the beam's angle precomputed (lidar_angle(n): the same float, from a per-beam table -- it is wave-uniform in the score
+// kernels and a correctly rounded division per lane and beam otherwise)
+__device__ __forceinline__ void clean_lidar_scan_at(float angle, float range, float theta, float &x, float &y)
+{
+    float rot = angle + theta;
     float s, c;
     sincosf_spec(rot, s, c);
     x = range * c;
     y = range * s;
+}
+__device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)
+{
+    clean_lidar_scan_at(lidar_angle(n), range, theta, x, y);
 }
 
 } // namespace pf

@@ -53,13 +53,15 @@ PF_HD void sincosf_spec(float x, float &s, float &c)
     pc = fma(pc, z, C2);
     pc = fma(pc, z, C1);
     double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-    // quadrant: n&1 swaps, bit 1 of n negates sin, bit 1 of (n+1) negates cos
-    double sv = (n & 1) ? cr : sr;
-    double cv = (n & 1) ? sr : cr;
+    // quadrant: n&1 swaps, bit 1 of n negates sin, bit 1 of (n+1) negates cos.  Done on the rounded floats: rounding to nearest
+    // commutes with negation and with selection, so the bits are those of selecting in double and rounding then
+    const float sf = (float)sr, cf = (float)cr;
+    float sv = (n & 1) ? cf : sf;
+    float cv = (n & 1) ? sf : cf;
     if (n & 2) sv = -sv;
     if ((n + 1) & 2) cv = -cv;
-    s = (float)sv;
-    c = (float)cv;
+    s = sv;
+    c = cv;
 }
 
 // natural log of a positive normal double: x = m 2^e, log m = 2 atanh((m-1)/(m+1))

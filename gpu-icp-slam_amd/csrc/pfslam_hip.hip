@@ -195,6 +195,7 @@ struct pfslam_handle {
     unsigned *cell_tab = nullptr;
     int *cell_list = nullptr, *cell_state = nullptr;
     uint4 *cell_pool = nullptr;
+    float *beam_angle = nullptr; // LIDAR_ANGLE(j), nb floats
 };
 
 // ==========================================================================================
@@ -257,6 +258,13 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     }
     if (CENSUS) pf::census_flush(cl, census);
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
+}
+
+// LIDAR_ANGLE(j) of every beam (kernel.cu:42), once per handle: the score kernels read it as a wave-uniform scalar
+__global__ void k_beam_angles(float *__restrict__ angle, int nb)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nb) angle[j] = pf::lidar_angle(j);
 }
 
 #include "kd_cells.hip.inc" // round 3: lattice-cell rows (k_cells_mark, k_cell_rows, k_score_kd_cells); beam_box is shared with k_plan
@@ -704,6 +712,9 @@ static int create_impl(pfslam_handle *h)
         h->gpose = h->pblk;
     }
     CHK(dalloc(&h->scan_base, (size_t)h->nb * PF_HDR_SLOTS));
+    CHK(dalloc(&h->beam_angle, (size_t)h->nb));
+    hipLaunchKernelGGL(k_beam_angles, dim3((h->nb + 255) / 256), dim3(256), 0, h->stream, h->beam_angle, h->nb);
+    HIPCHK(hipGetLastError());
     h->scan = h->scan_base;
     CHK(dalloc(&h->hot, (size_t)h->kd_cap)); CHK(dalloc(&h->parent, (size_t)h->kd_cap));
     CHK(dalloc(&h->kz, (size_t)h->kd_cap)); CHK(dalloc(&h->kw, (size_t)h->kd_cap));
@@ -835,6 +846,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->cell_list) (void)hipFree(h->cell_list);
     if (h->cell_state) (void)hipFree(h->cell_state);
     if (h->cell_pool) (void)hipFree(h->cell_pool);
+    if (h->beam_angle) (void)hipFree(h->beam_angle);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1232,7 +1244,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         CHK(dalloc(&h->cell_tab, (size_t)PF_CELL_WIN * PF_CELL_WIN));
         CHK(dalloc(&h->cell_list, (size_t)PF_CELL_LIST_CAP));
         CHK(dalloc(&h->cell_state, 16));
-        CHK(dalloc(&h->cell_pool, (size_t)PF_CELL_POOL_CAP));
+        CHK(dalloc(&h->cell_pool, (size_t)PF_CELL_POOL_CAP + PF_ROW_SLACK));
         HIPCHK(hipMemsetAsync(h->cell_tab, 0, (size_t)PF_CELL_WIN * PF_CELL_WIN * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->cell_state, 0, 64, h->stream));
     }
@@ -1281,14 +1293,11 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // the scan-match kernel itself; cen != nullptr: its counting instantiation (same launch shape, lane order, plan and results)
     auto scan_match = [&](pf::KdCensus *cen) {
         if (use_cells) {
-            if (cen)
-                hipLaunchKernelGGL((k_score_kd_cells<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                                   kd_view(h), geo, (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state,
-                                   order, direct, out, cen);
-            else
-                hipLaunchKernelGGL((k_score_kd_cells<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
-                                   kd_view(h), geo, (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state,
-                                   order, direct, out, (pf::KdCensus *)nullptr);
+#define PF_CELLS_ARGS grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const float *)h->beam_angle, h->nb, bpc, kd_view(h), geo, \
+                      (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state, order, direct, out
+            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true>), PF_CELLS_ARGS, cen);
+            else hipLaunchKernelGGL((k_score_kd_cells<false>), PF_CELLS_ARGS, (pf::KdCensus *)nullptr);
+#undef PF_CELLS_ARGS
         } else if (use_plan) {
             if (cen)
                 hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,

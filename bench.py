@@ -400,8 +400,12 @@ def main():
         # gather; a parent-hyperplane test one 16-byte + one 4-byte wave gather.  Bytes are lane-level: 64 lanes x record size.
         cen_timed = census_all[a.warmup:a.warmup + a.steps]
 
+        cells_kernel = bool(cell_stats["rows"])
+
         def per_launch(c):
-            g16, g4 = c["trips"] + c["tests"], c["tests"]
+            # wave-level gathers: 16-byte = descent-loop trips / row slots + the node record of a parent-hyperplane test; 4-byte = the
+            # parent index of such a test + (cell-row kernel, whose census books them in "uniform_trips") the cell-table words
+            g16, g4 = c["trips"] + c["tests"], c["tests"] + (c["uniform_trips"] if cells_kernel else 0)
             return g16, g4, g16 * 64 * 16 + g4 * 64 * 4
 
         pl = [per_launch(c) for c in cen_timed] or [(0, 0, 0)]
@@ -450,8 +454,11 @@ def main():
                        "oracle_min_wave_gathers": n_local / 64.0 * bvalid * vbar,
                        "note": "counted on the timed launches themselves: a second handle replays frames %d..%d (bit-identical state, "
                                "`replay_identical`) with the counting instantiation of the kernel behind every scoring pass; "
-                               "wave_gathers_per_launch = trips + 2 x tests = what TA_BUFFER_READ_WAVEFRONTS_sum counts for the same "
-                               "launches (pmc.census_over_pmc_wavefronts)" % (FIRST_FRAME, FIRST_FRAME + a.warmup + a.steps - 1)},
+                               "wave_gathers_per_launch = 16-byte + 4-byte wave gathers = what TA_BUFFER_READ_WAVEFRONTS_sum counts for "
+                               "the same launches (pmc.census_over_pmc_wavefronts).  Cell-row kernel: trips = row slots (requested four "
+                               "at a time) + node records of the generic tail, uniform_trips = cell-table words, prefix_trips = queries "
+                               "that found their cell's row, redescents = queries that went on generically"
+                               % (FIRST_FRAME, FIRST_FRAME + a.warmup + a.steps - 1)},
             "cells": dict(cell_stats, kernel_ms=plan_ms,
                           note="lattice-cell rows of the LAST timed launch (pfslam_cell_stats, csrc/kd_cells.hip.inc): cells under the waves' "
                                "beam-end boxes, one row per cell = the few nodes of the cell's first descent that can be nearest for some "
@@ -465,9 +472,9 @@ def main():
                           "4 B x 64 per parent-index gather; census of the timed launches, mean) / HIP-event time of the same launches "
                           "(mean); peak = wave-gather rate of this chip measured in this process (pfslam_ubench_gather: cache-resident "
                           "table, 8 waves/SIMD) x 1024 B; frac_of_nominal_peak prices the same bytes against CUs x 64 B/clk x clock.  "
-                          "With the shared-prefix plan most node visits are evaluated from scalar registers and issue no gather at all, "
-                          "and the gathers that remain are the divergent ones (several cache lines each), so `frac` is a LOWER bound "
-                          "of the gather path's load: pmc.ta_busy has the counter",
+                          "The cell-row kernel of round 3 replaced the per-query tree walk by a handful of row slots per query, and what "
+                          "binds it now is VALU issue (pmc.valu_issue_frac ~ 1): `frac` says how much of the gather path it still uses, "
+                          "not how far it is from its own ceiling",
             "ubench": dict(ub, note="the measured rate is what the same gather instruction sustains on this box, wave-uniform addresses"),
             "pmc": None if not pmc else {
                 "source": os.path.relpath(pmc_path, ROOT), "measured_clock_ghz": clock_ghz,
@@ -476,13 +483,17 @@ def main():
                 "ta_busy": (avgp["TA_TA_BUSY_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_TA_BUSY_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
                 "ta_cycles_frac": (avgp["TA_BUFFER_TOTAL_CYCLES_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_BUFFER_TOTAL_CYCLES_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
                 "valu_insts_per_simd_cycle": ((avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
+                "valu_issue_frac": (4.0 * (avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
                 "hbm": None if traffic is None else {"bytes_per_launch": traffic, "achieved": traffic / kern_s / 1e9, "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS},
                 "note": "rocprofv3 PMC passes of `python bench.py --no-cpu-baseline` (tools/profile_round.sh), averaged over the TIMED "
                         "launches of that process (dispatches [warmup, warmup + steps) of the timed instantiation).  ta_busy = TA_TA_BUSY_sum / CUs / (GRBM_GUI_ACTIVE / 8 XCDs); "
                         "ta_cycles_frac = TA_BUFFER_TOTAL_CYCLES_sum / CUs / kernel cycles; hbm = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 "
                         "correction of MI355X_MICROARCH.md) -- the map records are cache resident, compulsory HBM traffic is ~20 B per "
-                        "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement)"},
+                        "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement); "
+                        "valu_issue_frac = 4 cycles x VALU wave-instructions per SIMD / kernel cycles: the share of its issue cycles "
+                        "a SIMD spends on vector ALU instructions of this kernel (the cell-row kernel is bound by THIS, not by the "
+                        "gather path: see DESIGN.md section 4)"},
             "alg_equiv": {"bytes_per_eval": alg_bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                           "GBs": alg_bytes_per_eval * n_local / kern_s / 1e9,
                           "note": "SURVEY 8d's algorithmic node bytes (B_valid x V x 32 B + 20 B): served from L1/L2, "

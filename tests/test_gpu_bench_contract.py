@@ -109,4 +109,4 @@ def test_roofline_census_agrees_with_committed_pmc():
     pm = json.load(open(os.path.join(ROOT, p["source"])))
     frac_pmc = pm["avg_per_launch"]["TA_BUFFER_READ_WAVEFRONTS_sum"] * 1024.0 / (pm["kernel_ms"] * 1e-3) / 1e9 / r["peak"]
     assert abs(frac_pmc / r["frac_all_gathers_as_16B"] - 1.0) < 0.05, (frac_pmc, r["frac_all_gathers_as_16B"])
-    assert r["frac"] <= r["frac_all_gathers_as_16B"] <= 1.1 * r["frac"]
+    assert r["frac"] <= r["frac_all_gathers_as_16B"] <= 1.25 * r["frac"]   # the 4-byte gathers (cell-table words, parent indices) priced as 16-byte ones

@@ -172,6 +172,10 @@ void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line)
     exit(EXIT_FAILURE);
 }
 #define PFCHK(call, msg) checkPfslamErrorFn((call), msg, __FILE__, __LINE__)
+void checkCUDAErrorFn(const char *msg, const char *file, int line)
+{
+    if (g_handle) checkPfslamErrorFn(pfslam_synchronize(g_handle), msg, file, line); // cudaDeviceSynchronize + cudaGetLastError
+}
 
 void pfslamSetParticleCount(int n) { if (n > 0) g_particles = n; }
 

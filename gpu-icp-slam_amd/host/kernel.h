@@ -11,6 +11,25 @@
 struct uchar4 { unsigned char x, y, z, w; };
 #endif
 
+// The reference chooses between its GPU and CPU branches of the 2-D path at compile time (kernel.h:9-12; no #ifndef there, so
+// they cannot be overridden).  Every stage runs on the GPU here; the macros exist so that callers naming them still compile.
+#ifndef GPU_MOTION
+#define GPU_MOTION 1
+#endif
+#ifndef GPU_MEASUREMENT
+#define GPU_MEASUREMENT 1
+#endif
+#ifndef GPU_MAP
+#define GPU_MAP 1
+#endif
+#ifndef GPU_RESAMPLE
+#define GPU_RESAMPLE 1
+#endif
+
+// floor(log2 x) and ceil(log2 x) helpers of kernel.h:26-36 (x >= 1; ilog2(0) = 0 as there)
+inline int ilog2(int x) { return x > 1 ? 31 - __builtin_clz((unsigned)x) : 0; }
+inline int ilog2ceil(int x) { return ilog2(x - 1) + 1; }
+
 void particleFilterInit(Scene *scene);
 void particleFilterFree();
 void particleFilter(uchar4 *pbo, int frame, Lidar *lidar);
@@ -40,6 +59,8 @@ std::vector<std::pair<int, int>> pfslamLoopClosures();
 // (value + 128, one row per x).  Returns the number of exported points.
 int pfslamExportMap(const char *prefix);
 
-// error convention of the reference: print and exit (kernel.h:42-60)
+// error convention of the reference: print and exit (kernel.h:42-60).  checkCUDAErrorFn(msg, file, line) waits for the device
+// (every frame in flight is booked: a deferred error of the frame pipeline surfaces here) and exits on failure.
 void checkPfslamErrorFn(int rc, const char *msg, const char *file, int line);
-#define checkCUDAError(msg) checkPfslamErrorFn(0, msg, __FILE__, __LINE__)
+void checkCUDAErrorFn(const char *msg, const char *file, int line);
+#define checkCUDAError(msg) checkCUDAErrorFn(msg, __FILE__, __LINE__)

@@ -29,5 +29,19 @@ struct Patch { // 40 bytes
     MAP_TYPE *grid;
     unsigned char uid;
 };
+// topology graph of a map cluster (sceneStructs.h:47-60); the library keeps cluster 0's graph inside the handle
+// (pfslam_get_topology), these types are here for source compatibility with callers that name them
+struct Node { // graph node: position and path length to the current node
+    glm::vec2 pos;
+    float dist;
+};
+struct Cluster {
+    unsigned char id;
+    unsigned int nodeIdx;
+    std::vector<unsigned int> patchList;
+    std::vector<Node> nodes;
+    std::vector<std::vector<unsigned int>> edges;
+};
+static_assert(sizeof(Node) == 12, "graph node layout");
 static_assert(sizeof(Particle) == 32, "Particle must stay 32 bytes (getPCData hands out raw pointers)");
 static_assert(sizeof(Patch) == 40, "Patch layout");

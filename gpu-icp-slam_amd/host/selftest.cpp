@@ -25,6 +25,17 @@ int main(int argc, char **argv)
     printf("lidar %zu %zu %.6f %.6f\n", lidar.scans.size(), lidar.scans[0].size(), lidar.scans[0][0], lidar.scans.back().back());
     Pointcloud pc(argv[3]);
     printf("cloud %zu %.0f %.0f %.0f %.0f\n", pc.points.size(), pc.points[1].x, pc.points[1].y, pc.points[1].z, pc.points[1].w);
+    // the small helpers and macros of kernel.h:9-36 and the graph types of sceneStructs.h:47-60 exist for source compatibility
+    if (ilog2(1) != 0 || ilog2(2) != 1 || ilog2(1000) != 9 || ilog2ceil(1000) != 10 || ilog2ceil(1024) != 10 || ilog2ceil(1025) != 11) return 20;
+    if (!(GPU_MOTION && GPU_MEASUREMENT && GPU_MAP && GPU_RESAMPLE)) return 21;
+    {
+        Cluster c;
+        c.id = 0; c.nodeIdx = 0;
+        c.nodes.push_back(Node{glm::vec2(0.0f, 0.0f), 0.0f});
+        c.edges.push_back(std::vector<unsigned int>());
+        if (c.nodes.size() != 1 || sizeof(Node) != 12) return 22;
+    }
+    checkCUDAError("selftest"); // no handle yet: returns
     // KDTree facade == C-ABI
     std::vector<glm::vec4> pts;
     for (int i = 0; i < 257; i++) pts.push_back(glm::vec4((float)((i * 37) % 19) * 0.025f, (float)((i * 11) % 23) * 0.025f, 0.0f, (float)(i % 7)));

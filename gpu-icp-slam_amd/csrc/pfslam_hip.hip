@@ -196,6 +196,7 @@ struct pfslam_handle {
     int *cell_list = nullptr, *cell_state = nullptr;
     uint4 *cell_pool = nullptr;
     float *beam_angle = nullptr; // LIDAR_ANGLE(j), nb floats
+    float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
 };
 
 // ==========================================================================================
@@ -847,6 +848,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->cell_state) (void)hipFree(h->cell_state);
     if (h->cell_pool) (void)hipFree(h->cell_pool);
     if (h->beam_angle) (void)hipFree(h->beam_angle);
+    if (h->fit_acc) (void)hipFree(h->fit_acc);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1202,8 +1204,9 @@ static int score_chunks(const pfslam_handle *h)
 }
 
 struct ShardPack;
-__global__ void k_reduce_partials_minmax(const float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
-                                         const float *x, const float *y, const float *th, ShardPack *pack);
+__global__ void k_reduce_partials_minmax(float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
+                                         const float *x, const float *y, const float *th, ShardPack *pack, int wipe, unsigned *cell_tab,
+                                         const int *cell_list, int *cell_state);
 __global__ void k_shard_pack(const long long *stats, const float *x, const float *y, const float *th, int n, int goff, ShardPack *pack);
 __global__ void k_reduce_partials_minmax_wide(const float *partial, int n, int chunks, const int *order, float *fit, long long *stats);
 template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
@@ -1245,6 +1248,8 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         CHK(dalloc(&h->cell_list, (size_t)PF_CELL_LIST_CAP));
         CHK(dalloc(&h->cell_state, 16));
         CHK(dalloc(&h->cell_pool, (size_t)PF_CELL_POOL_CAP + PF_ROW_SLACK));
+        CHK(dalloc(&h->fit_acc, (size_t)h->n));
+        HIPCHK(hipMemsetAsync(h->fit_acc, 0, (size_t)h->n * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->cell_tab, 0, (size_t)PF_CELL_WIN * PF_CELL_WIN * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->cell_state, 0, 64, h->stream));
     }
@@ -1260,6 +1265,12 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         HIPCHK(hipGetLastError());
         order = h->order2;
     } // variant 1 = identity lane order
+    // cell-row kernel on a map with integer weights, several beam chunks, frame loop: the chunks ADD their sums to one accumulator
+    // per lane (exact in any order) instead of writing `used` partials per lane for the reduce kernel to read back (33 MB per frame)
+    // MEASURED AND OFF BY DEFAULT (PFSLAM_ACC_OUT=1 turns it on): the reduce kernel gets 10 us shorter and 33 MB of writes go away, but
+    // 8.4 M float atomics cost the scan-match kernel 30 us (0.626 -> 0.656 ms) -- plain stores retire for free next to VALU-bound work
+    static const bool acc_enabled = getenv("PFSLAM_ACC_OUT") && atoi(getenv("PFSLAM_ACC_OUT")) != 0;
+    const bool acc_out = acc_enabled && use_cells && h->integral_w && used > 1 && fuse_minmax && !census;
     const int direct = used > 1 ? 0 : 1;
     h->plan_valid = use_plan;
     h->cells_valid = use_cells;
@@ -1294,9 +1305,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     auto scan_match = [&](pf::KdCensus *cen) {
         if (use_cells) {
 #define PF_CELLS_ARGS grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const float *)h->beam_angle, h->nb, bpc, kd_view(h), geo, \
-                      (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state, order, direct, out
-            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true>), PF_CELLS_ARGS, cen);
-            else hipLaunchKernelGGL((k_score_kd_cells<false>), PF_CELLS_ARGS, (pf::KdCensus *)nullptr);
+                      (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state, order, direct
+            // a census replay BEHIND an accumulating pass must not add its (identical) sums a second time
+            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : 0, cen);
+            else hipLaunchKernelGGL((k_score_kd_cells<false>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : 0, (pf::KdCensus *)nullptr);
 #undef PF_CELLS_ARGS
         } else if (use_plan) {
             if (cen)
@@ -1345,7 +1357,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         scan_match(h->census_log + h->census_n++);
         HIPCHK(hipGetLastError());
     }
-    if (use_cells) { // wipe the pass's cells: the table is all zero between passes
+    // wipe the pass's cells (the table is all zero between passes): the frame loops' reduce kernel does it on the way
+    const bool clear_in_reduce = use_cells && used > 1 && fuse_minmax && !(used >= 256 && !shard_pack && h->goff == 0 && !acc_out);
+    if (use_cells && !clear_in_reduce) {
         hipLaunchKernelGGL(k_cells_clear, dim3(128), dim3(256), 0, h->stream, h->cell_tab, (const int *)h->cell_list, h->cell_state);
         HIPCHK(hipGetLastError());
     }
@@ -1354,13 +1368,15 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (!h->stats_clean) CHK(launch_stats_reset(h, h->stream));
         h->stats_clean = false;
     }
-    if (used >= 256 && fuse_minmax && !shard_pack && h->goff == 0) { // few particles, one beam per wave: 16 threads per particle
+    if (used >= 256 && fuse_minmax && !shard_pack && h->goff == 0 && !acc_out) { // few particles, one beam per wave: 16 threads per particle
         hipLaunchKernelGGL(k_reduce_partials_minmax_wide, dim3((h->n + 63) / 64), dim3(1024), 0, h->stream, h->partial, h->n, used, order,
                            h->fit, (long long *)h->stats);
         HIPCHK(hipGetLastError());
     } else if (used > 1 && fuse_minmax) {
-        hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->partial, h->n, used, order,
-                           h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th, shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr);
+        hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
+                           acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th,
+                           shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0,
+                           clear_in_reduce ? h->cell_tab : (unsigned *)nullptr, (const int *)h->cell_list, h->cell_state);
         HIPCHK(hipGetLastError());
     } else {
         if (used > 1) {

@@ -9,6 +9,7 @@
 #include "../../include/pfslam.h"
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -18,6 +19,59 @@ inline bool byX(const Pt &a, const Pt &b) { return a.x < b.x; }
 inline bool byY(const Pt &a, const Pt &b) { return a.y < b.y; }
 inline bool byZ(const Pt &a, const Pt &b) { return a.z < b.z; }
 
+// std::sort, on several threads, with std::sort's result.
+//
+// The permutation libstdc++'s std::sort leaves among tied keys IS the map's topology (kdtree.cpp:27,45-50 sort grid-snapped
+// coordinates: thousands of ties), so the sort cannot be replaced -- but it can be run in parallel: std::sort is
+// __introsort_loop (quicksort: median-of-three pivot, unguarded partition, the right part by recursion and the left part by
+// iteration, heapsort below the depth limit, ranges of <= 16 left alone) followed by __final_insertion_sort over the whole range.
+// What the loop does to a sub-range depends on that sub-range and its depth budget only, so the recursive call may as well run
+// on another thread; every partition, every swap and the final insertion pass are libstdc++'s own code, called with the
+// arguments std::sort would call them with.  The re-balance (KDTree::Balance every 100 frames, a full re-build on the host while
+// the GPU waits) is bounded by the first sorts of the build, which see the whole map on one thread otherwise.
+std::atomic<int> g_sort_threads{0};
+int sort_thread_budget()
+{
+    static const int n = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    return n;
+}
+template <typename It, typename Cmp>
+void par_introsort_loop(It first, It last, long depth_limit, Cmp comp)
+{
+    std::vector<std::thread> kids;
+    while (last - first > 16) { // _S_threshold
+        if (depth_limit == 0) {
+            std::__partial_sort(first, last, last, comp); // heapsort of the rest
+            break;
+        }
+        --depth_limit;
+        It cut = std::__unguarded_partition_pivot(first, last, comp);
+        if (last - cut > 16384 && g_sort_threads.fetch_add(1) < sort_thread_budget()) {
+            kids.emplace_back([=] {
+                par_introsort_loop(cut, last, depth_limit, comp);
+                g_sort_threads.fetch_sub(1);
+            });
+        } else {
+            if (last - cut > 16384) g_sort_threads.fetch_sub(1); // budget exhausted: undo the reservation
+            std::__introsort_loop(cut, last, depth_limit, comp);
+        }
+        last = cut;
+    }
+    for (auto &t : kids) t.join();
+}
+template <typename It, typename Cmp>
+void exact_sort(It first, It last, Cmp cmp)
+{
+    if (first == last) return;
+    if (last - first <= 32768) { // small: the library call itself
+        std::sort(first, last, cmp);
+        return;
+    }
+    auto comp = __gnu_cxx::__ops::__iter_comp_iter(cmp);
+    par_introsort_loop(first, last, (long)std::__lg(last - first) * 2, comp);
+    std::__final_insertion_sort(first, last, comp);
+}
+
 // `fork` > 0: the two sub-ranges are disjoint slices of `buf` and disjoint slices of `out` (pre-order layout), so
 // they are built on two threads; every sort still sees exactly the sequence the sequential build would give it,
 // hence the same (unstable-sort dependent) topology as the reference.
@@ -26,9 +80,9 @@ void build_range(std::vector<Pt> &buf, int lo, int hi, pfslam_node *out, int idx
     const int axis = parent < 0 ? 0 : (out[parent].axis + 1) % 3;
     auto first = buf.begin() + lo, last = buf.begin() + hi;
     switch (axis) {
-    case 0: std::sort(first, last, byX); break;
-    case 1: std::sort(first, last, byY); break;
-    default: std::sort(first, last, byZ); break;
+    case 0: exact_sort(first, last, byX); break;
+    case 1: exact_sort(first, last, byY); break;
+    default: exact_sort(first, last, byZ); break;
     }
     const int count = hi - lo, mid = count / 2;
     const Pt &m = buf[lo + mid];
@@ -53,7 +107,7 @@ extern "C" int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out)
     if (n == 0) return 0;
     std::vector<Pt> buf(n);
     for (int i = 0; i < n; i++) buf[i] = Pt{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
-    std::sort(buf.begin(), buf.end(), byX); // KDTree::Create pre-sorts on x before the recursive sort
+    exact_sort(buf.begin(), buf.end(), byX); // KDTree::Create pre-sorts on x before the recursive sort
     const unsigned hw = std::thread::hardware_concurrency();
     build_range(buf, 0, n, out, 0, -1, hw >= 16 ? 4 : hw >= 4 ? 2 : hw >= 2 ? 1 : 0); // up to 16 concurrent sub-builds
     return 0;

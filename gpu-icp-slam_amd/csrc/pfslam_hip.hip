@@ -11,7 +11,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <deque>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <chrono>
@@ -952,6 +954,21 @@ extern "C" int pfslam_set_variant(pfslam_handle *h, int variant)
     return 0;
 }
 
+// [0, n) in chunks on up to 16 threads (host-side passes over the whole map: the re-balance is a stall of the frame pipeline)
+template <typename F>
+static void parallel_chunks(int n, F fn)
+{
+    const int nt = (int)std::min<unsigned>(16u, std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)(n / 32768 + 1))));
+    if (nt <= 1) {
+        fn(0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) th.emplace_back([=] { fn(std::min(n, t * per), std::min(n, (t + 1) * per), t); });
+    for (auto &t : th) t.join();
+}
+
 // upload a tree: host mirror + split device layout.  Everything is validated and packed BEFORE the handle changes, so a
 // refused map leaves the previous one intact (host mirror, size and device arrays stay consistent).
 static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
@@ -969,37 +986,48 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     std::vector<uint4> hot(n);
     std::vector<int> par(n);
     std::vector<float> z(n), w(n);
-    int planar = 1;
-    bool integral = true;
-    for (int i = 0; i < n; i++) {
-        const pfslam_node &nd = nodes[i];
-        if (nd.axis < 0 || nd.axis > 2 || nd.left < -1 || nd.left >= n || nd.right < -1 || nd.right >= n ||
-            nd.parent < -1 || nd.parent >= n)
-            return fail("pfslam_set_map: node " + std::to_string(i) + " has out-of-range links or axis");
-        par[i] = nd.parent;
-        z[i] = nd.z;
-        w[i] = nd.w;
-        if (nd.z != 0.0f) planar = 0;
-        // |w| <= 2^13 keeps every partial sum of 1081 weights below 2^24, i.e. exact in any order
-        if (!(nd.w == (float)(int)nd.w && fabsf(nd.w) <= 8192.0f)) integral = false;
-    }
-    // on the lattice of the config?  x == fl(k * res) bit for bit, the way cell_to_point (ROUND_FRAC, kernel.cu:52) makes map points
-    bool lattice = planar != 0;
-    {
-        const float rx = h->cfg.map_res_x, ry = h->cfg.map_res_y, ix = 1.0f / rx, iy = 1.0f / ry;
-        for (int i = 0; i < n && lattice; i++) {
+    // pass 1 (parallel): links in range, planar, integer weights, on the lattice of the config -- x == fl(k * res) bit for bit, the way
+    // cell_to_point (ROUND_FRAC, kernel.cu:52) makes map points
+    std::atomic<int> bad{-1}, nonplanar{0}, nonintegral{0}, offlattice{0};
+    const float rx = h->cfg.map_res_x, ry = h->cfg.map_res_y, ix = 1.0f / rx, iy = 1.0f / ry;
+    parallel_chunks(n, [&](int lo, int hi, int) {
+        bool np = false, ni = false, ol = false;
+        for (int i = lo; i < hi; i++) {
             const pfslam_node &nd = nodes[i];
-            if (!(fabsf(nd.x) < 2e4f && fabsf(nd.y) < 2e4f)) { lattice = false; break; } // |k| < 2^20 at 2.5 cm; NaN fails
-            const float kx = roundf(nd.x * ix), ky = roundf(nd.y * iy);
-            lattice = (kx * rx == nd.x || (kx + 1.0f) * rx == nd.x || (kx - 1.0f) * rx == nd.x) &&
-                      (ky * ry == nd.y || (ky + 1.0f) * ry == nd.y || (ky - 1.0f) * ry == nd.y);
+            if (nd.axis < 0 || nd.axis > 2 || nd.left < -1 || nd.left >= n || nd.right < -1 || nd.right >= n || nd.parent < -1 || nd.parent >= n) {
+                int none = -1;
+                bad.compare_exchange_strong(none, i);
+                return;
+            }
+            par[i] = nd.parent;
+            z[i] = nd.z;
+            w[i] = nd.w;
+            np |= nd.z != 0.0f;
+            // |w| <= 2^13 keeps every partial sum of 1081 weights below 2^24, i.e. exact in any order
+            ni |= !(nd.w == (float)(int)nd.w && fabsf(nd.w) <= 8192.0f);
+            if (!ol) {
+                if (!(fabsf(nd.x) < 2e4f && fabsf(nd.y) < 2e4f)) ol = true; // |k| < 2^20 at 2.5 cm; NaN fails
+                else {
+                    const float kx = roundf(nd.x * ix), ky = roundf(nd.y * iy);
+                    ol = !((kx * rx == nd.x || (kx + 1.0f) * rx == nd.x || (kx - 1.0f) * rx == nd.x) &&
+                           (ky * ry == nd.y || (ky + 1.0f) * ry == nd.y || (ky - 1.0f) * ry == nd.y));
+                }
+            }
         }
-    }
-    for (int i = 0; i < n; i++) {
-        const pfslam_node &nd = nodes[i];
-        hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right, planar != 0);
-        if (planar && nd.axis == 2) memcpy(&z[i], &nd.left, 4); // true left child of a planar z-level node
-    }
+        if (np) nonplanar = 1;
+        if (ni) nonintegral = 1;
+        if (ol) offlattice = 1;
+    });
+    if (bad.load() >= 0) return fail("pfslam_set_map: node " + std::to_string(bad.load()) + " has out-of-range links or axis");
+    const int planar = nonplanar.load() ? 0 : 1;
+    const bool integral = nonintegral.load() == 0, lattice = planar && offlattice.load() == 0;
+    parallel_chunks(n, [&](int lo, int hi, int) { // pass 2: the hot records need `planar`
+        for (int i = lo; i < hi; i++) {
+            const pfslam_node &nd = nodes[i];
+            hot[i] = pf::pack_hot(nd.x, nd.y, nd.axis, nd.left, nd.right, planar != 0);
+            if (planar && nd.axis == 2) memcpy(&z[i], &nd.left, 4); // true left child of a planar z-level node
+        }
+    });
     HIPCHK(hipMemcpyAsync(h->hot, hot.data(), (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));

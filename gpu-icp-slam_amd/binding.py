@@ -19,7 +19,7 @@ SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
     "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_disperse", "pfslam_shard_score", "pfslam_shard_weights", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
-    "pfslam_set_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
+    "pfslam_set_particles", "pfslam_shift_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
@@ -104,6 +104,7 @@ def load():
     L.pfslam_set_map.argtypes = [vp, vp, i32]
     L.pfslam_set_particles.argtypes = [vp, vp, i32]
     L.pfslam_set_scan.argtypes = [vp, vp, i32]
+    L.pfslam_shift_particles.argtypes = [vp, vp]
     L.pfslam_set_pose.argtypes = [vp, vp]
     L.pfslam_set_grid.argtypes = [vp, vp, i32, i32]
     L.pfslam_motion_update.argtypes = [vp, i32]
@@ -257,6 +258,11 @@ class PfSlam:
         _chk(self.L.pfslam_synchronize(self._h), "pfslam_synchronize")
 
     # -- stages
+    def shift_particles(self, delta):
+        """Odometry hook: every particle and robotPos += (dx, dy, dtheta)."""
+        d = np.ascontiguousarray(delta, dtype=np.float32)
+        _chk(self.L.pfslam_shift_particles(self._h, _p(d)), "pfslam_shift_particles")
+
     def motion_update(self, frame):
         _chk(self.L.pfslam_motion_update(self._h, frame), "pfslam_motion_update")
 

@@ -141,7 +141,8 @@ struct pfslam_handle {
     std::vector<std::vector<unsigned>> topo_edges{std::vector<unsigned>()};
     unsigned topo_idx = 0;
     int *d_count = nullptr;
-    int topo_in_step = 0;               // pfslam_set_topology: UpdateTopology + CheckLoopClosure at the end of every frame
+    int topo_in_step = 0;               // pfslam_set_topology: UpdateTopology + CheckLoopClosure at the end of every frame (1) / with its booking (2)
+    hipStream_t topo_stream = nullptr;  // mode 2: the visibility counts of a frame being booked do not wait for the frames behind it
     std::vector<int32_t> frame_closures; // (candidate node, visible node) pairs proposed by the last frame
     // Frame pipeline.  A frame's kernels need nothing from the host (the map insert and the resample decision are taken on
     // the device), so pfslam_step only ENQUEUES frame t and then reads the header of frame t - lag: the host runs ahead of the
@@ -834,6 +835,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->topo_stream) { (void)hipStreamSynchronize(h->topo_stream); (void)hipStreamDestroy(h->topo_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_mapfork) (void)hipEventDestroy(h->ev_mapfork);
@@ -1211,6 +1213,29 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
     CHK(settle(h));
     hipLaunchKernelGGL(k_motion, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->w, h->wm,
                        h->n, frame, h->goff);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- odometry hook (no reference counterpart: the reference's filter has no motion model besides the diffusion) -------------
+__global__ __launch_bounds__(256) void k_shift(float *__restrict__ x, float *__restrict__ y, float *__restrict__ th, int n, float dx, float dy,
+                                               float dt, float *__restrict__ pose)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { pose[0] = pose[0] + dx; pose[1] = pose[1] + dy; pose[2] = pose[2] + dt; }
+    if (i >= n) return;
+    x[i] = x[i] + dx;
+    y[i] = y[i] + dy;
+    th[i] = th[i] + dt;
+}
+// Every pose the filter holds -- all particles and robotPos -- moves by the same increment (one float addition per component).
+// Enqueued behind the frames in flight; no host wait.
+extern "C" int pfslam_shift_particles(pfslam_handle *h, const float delta[3])
+{
+    if (!h || !delta) return fail("pfslam_shift_particles: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(join_map(h)); // the map update a frame left on the aux stream reads the pose
+    hipLaunchKernelGGL(k_shift, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, delta[0], delta[1], delta[2], h->pose);
     HIPCHK(hipGetLastError());
     return 0;
 }

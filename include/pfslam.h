@@ -132,6 +132,10 @@ int pfslam_set_grid(pfslam_handle *h, const int8_t *grid, int dimx, int dimy);
 
 /* ---- stage entry points (operate on the handle's device-resident state) ---- */
 int pfslam_motion_update(pfslam_handle *h, int frame);
+/* odometry hook (no reference counterpart: the reference's filter has no motion model besides the diffusion of kernel.cu:375-397):
+ * every pose the filter holds -- all particles and robotPos -- moves by delta = (dx, dy, dtheta), one float addition per
+ * component.  Enqueued behind the frames in flight, no host wait.  Sharded handles: call it on every rank. */
+int pfslam_shift_particles(pfslam_handle *h, const float delta[3]);
 /* fit_host may be NULL (result stays on the device; no synchronisation) */
 int pfslam_score_kd(pfslam_handle *h, float *fit_host);
 /* min/max/first-argmax of fit + weight update; outputs may be NULL */
@@ -165,7 +169,11 @@ int pfslam_traverse(pfslam_handle *h, const float *xyz_host, int n, int32_t *bes
  * check_loop_closure: pairs (candidate node j, visible node k) for every node j closer than 6 m on the map and
  *   farther than 20 m along the graph; returns the pair count in *n (pairs beyond cap are counted, not written).
  * get_topology: nodes as (x, y, dist) triples; *node_idx = index of the current node. */
-/* pfslam_set_topology(h, 1): pfslam_step and pfslam_step_grid then run UpdateTopology and CheckLoopClosure at the end of every
+/* pfslam_set_topology(h, 2): the same calls, made when the frame is BOOKED (`lag` steps after it was enqueued, see pfslam_step)
+ *   instead of at once: KD frames stay in flight (their visibility test reads the 2-D grid, which KD frames never write; the counts
+ *   run on a stream of their own), 2-D frames are still booked at once.  The graph and every frame's proposals are unchanged;
+ *   pfslam_get_closures returns those of the last booked frame (any getter books everything first).
+ * pfslam_set_topology(h, 1): pfslam_step and pfslam_step_grid then run UpdateTopology and CheckLoopClosure at the end of every
  *   frame, exactly where the reference has the two calls commented out (kernel.cu:1750-1751); pfslam_get_closures returns the
  *   pairs the LAST frame proposed (count in *n; pairs beyond cap are counted, not written).  In the KD frame loop FindWalls
  *   reads the 2-D grid the KD path never updates (dev_occupancyGrid, kernel.cu:680: all -100, every node visible); in the 2-D

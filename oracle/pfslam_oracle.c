@@ -1512,6 +1512,17 @@ void orc_slam_set_particles(orc_slam *s, const orc_particle *p)
     memcpy(s->dev, p, sizeof(orc_particle) * (size_t)s->cfg.n_particles);
     memcpy(s->host, p, sizeof(orc_particle) * (size_t)s->cfg.n_particles);
 }
+/* odometry hook of the harness (no reference counterpart: the reference's filter has no motion model besides the diffusion of
+ * kernel.cu:375-397): every pose the filter holds -- all particles, both copies, and robotPos -- moves by the same increment,
+ * one float addition per component */
+void orc_slam_shift_particles(orc_slam *s, const float d[3])
+{
+    for (int i = 0; i < s->cfg.n_particles; i++) {
+        s->dev[i].x = s->dev[i].x + d[0]; s->dev[i].y = s->dev[i].y + d[1]; s->dev[i].theta = s->dev[i].theta + d[2];
+        s->host[i].x = s->dev[i].x; s->host[i].y = s->dev[i].y; s->host[i].theta = s->dev[i].theta;
+    }
+    for (int k = 0; k < 3; k++) s->robot[k] = s->robot[k] + d[k];
+}
 void orc_slam_get_pose(const orc_slam *s, float pose[3]) { memcpy(pose, s->robot, 12); }
 int orc_slam_kd_size(const orc_slam *s) { return s->kd_size; }
 const orc_node *orc_slam_tree(const orc_slam *s) { return s->kd; }

@@ -177,6 +177,7 @@ void orc_slam_step_grid_cpu(orc_slam *s, int frame, const float *scan);
 void orc_slam_set_grid(orc_slam *s, const int8_t *grid);
 const int8_t *orc_slam_grid(orc_slam *s);
 void orc_slam_set_particles(orc_slam *s, const orc_particle *p); /* device array and host mirror */
+void orc_slam_shift_particles(orc_slam *s, const float d[3]);       /* odometry hook: particles and robotPos += d */
 void orc_slam_get_pose(const orc_slam *s, float pose[3]);
 int orc_slam_kd_size(const orc_slam *s);
 const orc_node *orc_slam_tree(const orc_slam *s);

@@ -65,3 +65,40 @@ def run(engine, make_particles, frame_scans, grid_path=False, n_frames=N_FRAMES)
         pairs = engine.closures()
         rec.append((tuple(pose.view(np.int32).tolist()), int(t.get("kd_size", 0)), int(t["resampled"]), tuple(map(tuple, pairs.tolist()))))
     return rec
+
+
+# ---- free-running variant (golden_v4): no re-centring of the cloud -----------------------------------------------------------
+# The robot starts at the origin of ITS OWN map frame (the first scan seeds the map at robotPos = 0, kernel.cu:1714-1717) and the
+# harness hands the filter the commanded motion of every frame as an odometry increment -- a rigid shift of every pose the filter
+# holds (pfslam_shift_particles; the reference's filter has no motion model besides its 1.5 cm diffusion).  The particle cloud is
+# never replaced: diversity, weights and resampling history carry over from frame to frame, 100 000 particles.
+N_PARTICLES_FREE = 100000
+
+
+def trajectory_free(n_frames=N_FRAMES):
+    """The square loop of `trajectory` in the robot's start frame: pose 0 = (0, 0, 0)."""
+    t = trajectory(n_frames)
+    return [np.array([p[0] - t[0][0], p[1] - t[0][1], p[2] - t[0][2]], np.float32) for p in t]
+
+
+def run_free(engine, frame_scans, grid_path=False, n_frames=N_FRAMES, look_every=1, topology_mode=1):
+    """Free-running closed loop: shift by the commanded motion, step.  records[f] as in `run`; the engine is only looked at every
+    `look_every` frames (in between the frames stay enqueued -- with the topology calls inside the frame loop they are booked at
+    once anyway; topology_mode 2 = the product's lagged booking, pfslam_set_topology)."""
+    engine.set_topology(topology_mode)
+    traj = trajectory_free(n_frames)
+    rec = []
+    for f in range(1, n_frames + 1):
+        if f > 1:
+            engine.shift_particles(traj[f - 1] - traj[f - 2])
+        if grid_path:
+            engine.step_grid(f, frame_scans[f - 1])
+        else:
+            engine.step(f, frame_scans[f - 1])
+        if f % look_every and f != n_frames:
+            continue
+        t = engine.trace()
+        pose = np.asarray(engine.pose, np.float32)
+        pairs = engine.closures()
+        rec.append((tuple(pose.view(np.int32).tolist()), int(t.get("kd_size", 0)), int(t["resampled"]), tuple(map(tuple, pairs.tolist()))))
+    return rec

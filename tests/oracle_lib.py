@@ -107,6 +107,7 @@ def lib():
     L.orc_slam_topology.restype = vp; L.orc_slam_topology.argtypes = [vp]
     L.orc_slam_grid.restype = vp; L.orc_slam_grid.argtypes = [vp]
     L.orc_slam_set_particles.restype = None; L.orc_slam_set_particles.argtypes = [vp, vp]
+    L.orc_slam_shift_particles.restype = None; L.orc_slam_shift_particles.argtypes = [vp, vp]
     L.orc_slam_get_pose.restype = None; L.orc_slam_get_pose.argtypes = [vp, vp]
     L.orc_slam_kd_size.restype = i32; L.orc_slam_kd_size.argtypes = [vp]
     L.orc_slam_tree.restype = vp; L.orc_slam_tree.argtypes = [vp]
@@ -249,6 +250,9 @@ class Slam:
     def set_particles(self, p):
         assert len(p) == self.n
         lib().orc_slam_set_particles(self.h, P(np.ascontiguousarray(p)))
+
+    def shift_particles(self, delta):
+        lib().orc_slam_shift_particles(self.h, P(np.ascontiguousarray(delta, dtype=np.float32)))
 
     def step_grid(self, frame, scan):
         scan = np.ascontiguousarray(scan, dtype=np.float32)

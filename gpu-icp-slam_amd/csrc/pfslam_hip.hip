@@ -1289,9 +1289,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     const int *order = nullptr;
     // How the scoring pass is organised (results are bit-identical): variant 0 = default; 1 = identity lane order; 2 = plain per-lane
     // traversal; 3 = plan / cell rows at any particle count; 4 = the round-2 shared-prefix plan instead of cell rows (A/B, tests).
-    // With few particles neither pays for its extra launches: measured break-even of the plan ~6 k particles (scoring pass at
-    // 5 k / 10 k / 50 k particles: 0.203 / 0.313 / 0.841 ms with the plan, 0.198 / 0.353 / 1.327 ms without).
-    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 6144;
+    // With few particles neither pays for its extra launches (~0.1 ms of marking + rows): measured scoring pass at 3 k / 5 k / 10 k /
+    // 50 k particles: cell rows 0.175 / 0.185 / 0.251 / 0.502 ms, plan 0.162 / 0.204 / 0.312 / 0.825 ms, plain traversal 0.139 / 0.198 /
+    // 0.351 / 1.307 ms (tools/experiments/r03/cells_threshold.py): organised from ~4.6 k particles on.
+    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 4608;
     const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
     const bool use_cells = organised && h->lattice_ok && h->variant != 4; // lattice-cell rows (kd_cells.hip.inc)
     const bool use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);

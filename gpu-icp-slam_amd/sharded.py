@@ -116,10 +116,17 @@ class ShardedSlam:
         e, b = self.eng, self.buf
         if e.shard_disperse(frame, scan):       # first scan seeds the map (kernel.cu:1714-1717); replicated
             return
+        if self.world == 1:                     # buffers 10 / 17 alias 5 / 16: only the record moves (to its gathered slot)
+            self.collectives += 3
+            e.shard_score()
+            b.packs.copy_(b.pack)
+            e.shard_weights()
+            e.shard_finish()
+            return
         local, glob = b.pose_blocks()           # the local block alternates between two allocations: ask every frame
         # the poses are final: gather them now; the collective runs on its own stream under the score kernel
         p_pose = self._all_gather(glob, local, async_op=True)
-        e.shard_score()                         # lane order, plan, scan-match, reduce -> this shard's 32-byte record
+        e.shard_score()                         # lane order, cell rows, scan-match, reduce -> this shard's 32-byte record
         self._all_gather(b.packs, b.pack)       # 32 bytes per rank: keys + pose of every shard's best particle
         e.shard_weights()                       # global min / max / argmax, weights, pose = best + ICP increment; map lists start
         p_w = self._all_gather(b.gw, b.w, async_op=True)   # the weights are final: gathered under the map update

@@ -247,7 +247,7 @@ int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
  *   parent-hyperplane tests (one 4-byte + one 16-byte wave gather each), out[3] lanes in them, out[4] trips in which every
  *   active lane stood on the same node, out[5] those of them on the common path of all 64 lanes from the root.
  * pfslam_set_variant: how the scoring pass is organised (results are bit-identical; A/B measurements and tests): 0 = default
- *   (lanes along a Hilbert curve: counting sort over cells of the cloud; from ~6 k particles on a planar map: lattice-cell rows
+ *   (lanes along a Hilbert curve: counting sort over cells of the cloud; from ~4.6 k particles on a planar map: lattice-cell rows
  *   when every map point lies on the lattice k * resolution -- true of every map the SLAM step builds --, the round-2
  *   shared-prefix plan otherwise), 1 = identity lane order, 2 = the plain per-lane traversal, 3 = cell rows / plan at any
  *   particle count, 4 = like 3 but always the shared-prefix plan.  The environment variable PFSLAM_VARIANT sets the initial value. */

@@ -511,8 +511,9 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     if (cs && blockIdx.x == 0 && threadIdx.x == 0) {
         for (int k = 0; k < 8; k++) cs[k] = 0;
         const bool fin = fabsf(mx) < 1e6f && fabsf(my) < 1e6f; // NaN poses among the first slots: any window will do
-        cs[2] = (fin ? lattice_floor(mx, geo.resx, geo.invx) : 0) - PF_CELL_WIN / 2;
-        cs[3] = (fin ? lattice_floor(my, geo.resy, geo.invy) : 0) - PF_CELL_WIN / 2;
+        // in sub-cell units, on a whole cell (even)
+        cs[2] = PF_CELL_SUB * (fin ? lattice_floor(mx, geo.resx, geo.invx) : 0) - PF_CELL_WIN / 2;
+        cs[3] = PF_CELL_SUB * (fin ? lattice_floor(my, geo.resy, geo.invy) : 0) - PF_CELL_WIN / 2;
     }
     float vx = 0, vy = 0, vt = 0;
     for (int k = threadIdx.x; k < ns; k += 256) {
@@ -1587,8 +1588,8 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
     return 0;
 }
 
-// the lattice-cell rows of the LAST scoring pass: out[0] cells marked, [1] rows built, [2] mean first-descent candidates per row,
-// [3] mean re-descent candidates per row, [4] marked cells left without a row (too many candidates / pool exhausted: generic lanes),
+// the lattice-cell rows of the LAST scoring pass: out[0] lattice cells marked, [1] rows built (one per sub-cell: four per marked cell), [2] mean first-descent candidates per row,
+// [3] mean re-descent candidates per row, [4] sub-cells left without a row (too many candidates / pool exhausted: generic lanes),
 // [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell.  All zero when the pass did not use cell rows.
 extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[8])
 {

@@ -22,6 +22,20 @@ namespace pf {
 PF_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
 PF_HD float fdiv(float a, float b) { return a / b; }
 
+// fma(a, b, c) whose addend c is a loop-invariant constant: the compiler turns such an fma into the two-address v_fmac_f64 and pays a
+// 64-bit register copy of the constant in front of every one of them (ten per sincos in the scan-match loop, 5 % of that kernel's
+// VALU work); the three-address form needs none.  Same operation, same bits.
+PF_HD double fma_const_addend(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fma(a, b, c);
+#endif
+}
+
 // sin and cos of a float argument: Cody-Waite reduction by pi/2 (33+53-bit constants,
 // exact for |x| < 1e6), fdlibm kernel polynomials, all in double with explicit fma.
 PF_HD void sincosf_spec(float x, float &s, float &c)
@@ -41,17 +55,17 @@ PF_HD void sincosf_spec(float x, float &s, float &c)
     r = fma(-fn, PIO2_1T, r);
     int n = (int)fn;
     double z = r * r;
-    double ps = fma(S6, z, S5);
-    ps = fma(ps, z, S4);
-    ps = fma(ps, z, S3);
-    ps = fma(ps, z, S2);
-    ps = fma(ps, z, S1);
+    double ps = fma_const_addend(S6, z, S5);
+    ps = fma_const_addend(ps, z, S4);
+    ps = fma_const_addend(ps, z, S3);
+    ps = fma_const_addend(ps, z, S2);
+    ps = fma_const_addend(ps, z, S1);
     double sr = fma(r * z, ps, r);
-    double pc = fma(C6, z, C5);
-    pc = fma(pc, z, C4);
-    pc = fma(pc, z, C3);
-    pc = fma(pc, z, C2);
-    pc = fma(pc, z, C1);
+    double pc = fma_const_addend(C6, z, C5);
+    pc = fma_const_addend(pc, z, C4);
+    pc = fma_const_addend(pc, z, C3);
+    pc = fma_const_addend(pc, z, C2);
+    pc = fma_const_addend(pc, z, C1);
     double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
     // quadrant: n&1 swaps, bit 1 of n negates sin, bit 1 of (n+1) negates cos.  Done on the rounded floats: rounding to nearest
     // commutes with negation and with selection, so the bits are those of selecting in double and rounding then

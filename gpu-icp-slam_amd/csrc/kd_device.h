@@ -280,25 +280,30 @@ static_assert(sizeof(KdPlanRow) == 16 + 16 * PF_PLAN_CAND, "plan row layout");
 
 struct KdGroupBox { float xlo, xhi, ylo, yhi, tlo, thi; int count, pad; }; // pose bounding box of a wave's 64 particles
 
-// LIDAR_ANGLE(i) (kernel.cu:42) + CleanLidarScan (kernel.cu:182-187)
+// LIDAR_ANGLE(i) (kernel.cu:42) + CleanLidarScan (kernel.cu:182-187).  cos / sin of rot = angle + theta by the angle-addition
+// specification of pf_math.h (sincos_sum_spec).
 __device__ __forceinline__ float lidar_angle(int n)
 {
     const float PI_F = 3.1415926535897932384626422832795028841971f; // utilities.h:12
     return fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f);
 }
-// with the beam's angle precomputed (lidar_angle(n): the same float, from a per-beam table -- it is wave-uniform in the score
-// kernels and a correctly rounded division per lane and beam otherwise)
-__device__ __forceinline__ void clean_lidar_scan_at(float angle, float range, float theta, float &x, float &y)
+// the hot loops: the beam's angle and parts from a per-beam table (wave-uniform scalars), the heading's parts once per particle
+__device__ __forceinline__ void clean_lidar_scan_parts(float angle, const AngleParts &A, float range, float theta, const AngleParts &T,
+                                                       float &x, float &y)
 {
-    float rot = angle + theta;
+    const float rot = angle + theta;
     float s, c;
-    sincosf_spec(rot, s, c);
+    sincos_sum_spec(A, T, rot, s, c);
     x = range * c;
     y = range * s;
 }
 __device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)
 {
-    clean_lidar_scan_at(lidar_angle(n), range, theta, x, y);
+    const float angle = lidar_angle(n);
+    clean_lidar_scan_parts(angle, angle_parts(angle), range, theta, angle_parts(theta), x, y);
 }
+// per-beam table entry: {cos, sin, angle as double, angle as float (low half of the 4th double's slot)}
+struct BeamParts { double c, s, a; float angle, pad; };
+static_assert(sizeof(BeamParts) == 32, "beam table entry");
 
 } // namespace pf

@@ -38,7 +38,8 @@ PF_HD double fma_const_addend(double a, double b, double c)
 
 // sin and cos of a float argument: Cody-Waite reduction by pi/2 (33+53-bit constants,
 // exact for |x| < 1e6), fdlibm kernel polynomials, all in double with explicit fma.
-PF_HD void sincosf_spec(float x, float &s, float &c)
+// sincos_core: the reduced kernels sr = sin(r), cr = cos(r) and the quadrant n.
+PF_HD void sincos_core(float x, double &sr, double &cr, int &n)
 {
     const double TWO_OVER_PI = 6.36619772367581382433e-01;
     const double PIO2_1 = 1.57079632673412561417e+00;
@@ -53,20 +54,26 @@ PF_HD void sincosf_spec(float x, float &s, float &c)
     double fn = rint(xd * TWO_OVER_PI);
     double r = fma(-fn, PIO2_1, xd);
     r = fma(-fn, PIO2_1T, r);
-    int n = (int)fn;
+    n = (int)fn;
     double z = r * r;
     double ps = fma_const_addend(S6, z, S5);
     ps = fma_const_addend(ps, z, S4);
     ps = fma_const_addend(ps, z, S3);
     ps = fma_const_addend(ps, z, S2);
     ps = fma_const_addend(ps, z, S1);
-    double sr = fma(r * z, ps, r);
+    sr = fma(r * z, ps, r);
     double pc = fma_const_addend(C6, z, C5);
     pc = fma_const_addend(pc, z, C4);
     pc = fma_const_addend(pc, z, C3);
     pc = fma_const_addend(pc, z, C2);
     pc = fma_const_addend(pc, z, C1);
-    double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+}
+PF_HD void sincosf_spec(float x, float &s, float &c)
+{
+    double sr, cr;
+    int n;
+    sincos_core(x, sr, cr, n);
     // quadrant: n&1 swaps, bit 1 of n negates sin, bit 1 of (n+1) negates cos.  Done on the rounded floats: rounding to nearest
     // commutes with negation and with selection, so the bits are those of selecting in double and rounding then
     const float sf = (float)sr, cf = (float)cr;
@@ -76,6 +83,46 @@ PF_HD void sincosf_spec(float x, float &s, float &c)
     if ((n + 1) & 2) cv = -cv;
     s = sv;
     c = cv;
+}
+// the same as doubles (~1e-16), before any rounding to float
+PF_HD void sincos_d(float x, double &s, double &c)
+{
+    double sr, cr;
+    int n;
+    sincos_core(x, sr, cr, n);
+    double sv = (n & 1) ? cr : sr;
+    double cv = (n & 1) ? sr : cr;
+    if (n & 2) sv = -sv;
+    if ((n + 1) & 2) cv = -cv;
+    s = sv;
+    c = cv;
+}
+
+// cos / sin of rot = fl(angle + theta), the float sum CleanLidarScan forms (kernel.cu:183-186), by angle addition in double:
+//   cos(A + T + d) = cos(A + T) (1 - d^2 / 2) - sin(A + T) d,    d = rot - (A + T) = the rounding error of the float sum,
+// with cos / sin of the two float arguments from sincos_d.  A fixed sequence of IEEE double operations like the rest of this
+// file (same bits on gfx950 and x86-64; restated in oracle/pfslam_oracle.c), accurate to a few 1e-16 before the one rounding to
+// float.  The beam's part comes from a per-beam table, the heading's part is computed once per particle: the scan-match loop pays
+// 14 double operations per end point instead of an argument reduction and two degree-6 polynomials.
+struct AngleParts { double c, s, a; }; // cos, sin of a float angle and the angle itself, as doubles
+PF_HD AngleParts angle_parts(float angle)
+{
+    AngleParts p;
+    sincos_d(angle, p.s, p.c);
+    p.a = (double)angle;
+    return p;
+}
+PF_HD void sincos_sum_spec(const AngleParts &A, const AngleParts &T, float rot, float &s, float &c)
+{
+    const double at = A.a + T.a;
+    const double d = (double)rot - at;
+    const double c0 = fma(-A.s, T.s, A.c * T.c);
+    const double s0 = fma(A.c, T.s, A.s * T.c);
+    const double h = -0.5 * (d * d);
+    const double c1 = fma(-d, s0, c0);
+    const double s1 = fma(d, c0, s0);
+    c = (float)fma(h, c0, c1);
+    s = (float)fma(h, s0, s1);
 }
 
 // natural log of a positive normal double: x = m 2^e, log m = 2 atanh((m-1)/(m+1))

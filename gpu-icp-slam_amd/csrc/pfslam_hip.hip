@@ -198,7 +198,7 @@ struct pfslam_handle {
     unsigned *cell_tab = nullptr;
     int *cell_list = nullptr, *cell_state = nullptr;
     uint4 *cell_pool = nullptr;
-    float *beam_angle = nullptr; // LIDAR_ANGLE(j), nb floats
+    pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
 };
 
@@ -228,6 +228,23 @@ __global__ __launch_bounds__(256) void k_motion(float *__restrict__ x, float *__
     th[i] += nt;
 }
 
+// LIDAR_ANGLE(j) of every beam (kernel.cu:42) and its cos / sin as doubles, once per handle: the score kernels read them as
+// wave-uniform scalars (sincos_sum_spec, pf_math.h)
+__global__ void k_beam_angles(pf::BeamParts *__restrict__ beams, int nb)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    const float angle = pf::lidar_angle(j);
+    const pf::AngleParts p = pf::angle_parts(angle);
+    beams[j] = pf::BeamParts{p.c, p.s, p.a, angle, 0.0f};
+}
+__device__ __forceinline__ void beam_end_point(const pf::BeamParts *__restrict__ beams, int j, float range, float theta, const pf::AngleParts &T,
+                                               float &x, float &y)
+{
+    const pf::BeamParts bp = beams[j]; // wave-uniform: scalar loads
+    pf::clean_lidar_scan_parts(bp.angle, pf::AngleParts{bp.c, bp.s, bp.a}, range, theta, T, x, y);
+}
+
 // ---- A5: scan-match score (EvaluateParticleKD / kernEvaluateParticlesKD, kernel.cu:1198-1308)
 // Lane = particle, the wave walks a chunk of beams: all 64 lanes query the same beam from
 // near-identical poses, so their descents touch the same nodes until the last levels (one
@@ -237,8 +254,8 @@ __global__ __launch_bounds__(256) void k_motion(float *__restrict__ x, float *__
 template <bool PLANAR, bool CENSUS = false>
 __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, const float *__restrict__ py,
                                                   const float *__restrict__ pth, int n,
-                                                  const float *__restrict__ scan, int nb, int beams_per_chunk,
-                                                  pf::KdView tree, const int *__restrict__ order, int direct,
+                                                  const float *__restrict__ scan, const pf::BeamParts *__restrict__ beams, int nb,
+                                                  int beams_per_chunk, pf::KdView tree, const int *__restrict__ order, int direct,
                                                   float *__restrict__ out, pf::KdCensus *__restrict__ census = nullptr)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,11 +265,12 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     // lane -> particle through the Hilbert order: the 64 lanes of a wave hold neighbouring poses
     const int i = order ? order[slot] : slot;
     const float x = px[i], y = py[i], th = pth[i];
+    const pf::AngleParts T = pf::angle_parts(th); // the heading's part of every end point of this lane
     float acc = 0.0f;
     pf::KdCensusLocal cl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = j0; j < j1; j++) {
         float wx, wy;
-        pf::clean_lidar_scan(j, scan[j], th, wx, wy);
+        beam_end_point(beams, j, scan[j], th, T, wx, wy);
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;
             wy += y;
@@ -262,13 +280,6 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     }
     if (CENSUS) pf::census_flush(cl, census);
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
-}
-
-// LIDAR_ANGLE(j) of every beam (kernel.cu:42), once per handle: the score kernels read it as a wave-uniform scalar
-__global__ void k_beam_angles(float *__restrict__ angle, int nb)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nb) angle[j] = pf::lidar_angle(j);
 }
 
 #include "kd_cells.hip.inc" // round 3: lattice-cell rows (k_cells_mark, k_cell_rows, k_score_kd_cells); beam_box is shared with k_plan
@@ -395,7 +406,8 @@ __device__ __forceinline__ void plan_visit(const float4 cd, float wx, float wy, 
 
 template <bool CENSUS = false>
 __global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ px, const float *__restrict__ py,
-                                                      const float *__restrict__ pth, int n, const float *__restrict__ scan, int nb,
+                                                      const float *__restrict__ pth, int n, const float *__restrict__ scan,
+                                                      const pf::BeamParts *__restrict__ beams, int nb,
                                                       int beams_per_chunk, pf::KdView tree, const pf::KdPlanRow *__restrict__ plan,
                                                       const int *__restrict__ order, int direct, float *__restrict__ out,
                                                       pf::KdCensus *__restrict__ census = nullptr)
@@ -406,6 +418,7 @@ __global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ 
     if (slot >= n) return;
     const int i = order ? order[slot] : slot;
     const float x = px[i], y = py[i], th = pth[i];
+    const pf::AngleParts T = pf::angle_parts(th);
     float acc = 0.0f;
     pf::KdCensusLocal cl = {0, 0, 0, 0, 0, 0, 0, 0};
     const pf::KdPlanRow *rows = plan + (size_t)g * nb; // wave-uniform addresses: scalar loads
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ 
             cur = nxt;
             continue;
         }
-        pf::clean_lidar_scan(j, cur.range, th, wx, wy);
+        beam_end_point(beams, j, cur.range, th, T, wx, wy);
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;
             wy += y;
@@ -1359,7 +1372,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // the scan-match kernel itself; cen != nullptr: its counting instantiation (same launch shape, lane order, plan and results)
     auto scan_match = [&](pf::KdCensus *cen) {
         if (use_cells) {
-#define PF_CELLS_ARGS grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const float *)h->beam_angle, h->nb, bpc, kd_view(h), geo, \
+#define PF_CELLS_ARGS grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc, kd_view(h), geo, \
                       (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state, order, direct
             // a census replay BEHIND an accumulating pass must not add its (identical) sums a second time
             if (cen) hipLaunchKernelGGL((k_score_kd_cells<true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : 0, cen);
@@ -1367,22 +1380,22 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
 #undef PF_CELLS_ARGS
         } else if (use_plan) {
             if (cen)
-                hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
                                    kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, cen);
             else
-                hipLaunchKernelGGL((k_score_kd_plan<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+                hipLaunchKernelGGL((k_score_kd_plan<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
                                    kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, (pf::KdCensus *)nullptr);
         } else if (h->planar && cen)
-            hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+            hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
                                kd_view(h), order, direct, out, cen);
         else if (cen)
-            hipLaunchKernelGGL((k_score_kd<false, true>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+            hipLaunchKernelGGL((k_score_kd<false, true>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
                                kd_view(h), order, direct, out, cen);
         else if (h->planar)
-            hipLaunchKernelGGL((k_score_kd<true, false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+            hipLaunchKernelGGL((k_score_kd<true, false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
                                kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
         else
-            hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, h->nb, bpc,
+            hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
                                kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
     };
     if (use_plan || use_cells) {

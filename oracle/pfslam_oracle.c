@@ -16,6 +16,7 @@
  */
 #include "pfslam_oracle.h"
 
+#include <pthread.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -97,7 +98,8 @@ float orc_normal(uint32_t *state, float mean, float stddev)
 /* bits.  Accuracy ~1e-16 before the final rounding to float, i.e. the   */
 /* correctly rounded float result except in ~1e-8 of arguments.          */
 /* ------------------------------------------------------------------ */
-void orc_sincosf(float x, float *s, float *c)
+/* sin and cos of a float argument as doubles (~1e-16): what orc_sincosf rounds to float */
+void orc_sincos_d(float x, double *s, double *c)
 {
     /* Cody-Waite reduction by pi/2 (2 constants, 33+53 bits), fdlibm kernel polynomials */
     static const double TWO_OVER_PI = 6.36619772367581382433e-01;
@@ -136,8 +138,15 @@ void orc_sincosf(float x, float *s, float *c)
     case 2: sv = -sr; cv = -cr; break;
     default: sv = -cr; cv = sr; break;
     }
-    *s = (float)sv;
-    *c = (float)cv;
+    *s = sv;
+    *c = cv;
+}
+void orc_sincosf(float x, float *s, float *c)
+{
+    double sd, cd;
+    orc_sincos_d(x, &sd, &cd);
+    *s = (float)sd;
+    *c = (float)cd;
 }
 
 double orc_log(double x)
@@ -365,13 +374,69 @@ void orc_add_noise(orc_particle *p, int n, int frame, int global_idx0)
 /* ------------------------------------------------------------------ */
 /* A4  CleanLidarScan (kernel.cu:182-187), LIDAR_ANGLE (kernel.cu:42)  */
 /* ------------------------------------------------------------------ */
-void orc_clean_lidar_scan(int n, float scan, float theta, float *x, float *y)
+/* cos / sin of rot = fl(angle + theta), the float sum the reference forms (kernel.cu:183-186), by angle addition in double:
+ *   cos(A + T + d) = cos(A + T) (1 - d^2 / 2) - sin(A + T) d,   d = rot - (A + T) = the rounding error of the float sum,
+ * with cos / sin of the two float arguments from orc_sincos_d.  A fixed sequence of IEEE double operations like everything
+ * else here (same bits on x86-64 and gfx950), accurate to a few 1e-16 before the one rounding to float -- still far inside the
+ * 1-2 ulp of any libm cosf.  Why: the beam angle's part is a per-beam table and the heading's part is computed once per
+ * particle, so the product's scan-match loop pays 14 double operations per end point instead of 26 + an argument reduction. */
+typedef struct { double c, s, a; } orc_angle_parts;
+static orc_angle_parts orc_parts(float angle)
 {
-    float rot = (-135.0f + n * .25f) * ORC_PI / 180 + theta;
+    orc_angle_parts p;
+    orc_sincos_d(angle, &p.s, &p.c);
+    p.a = (double)angle;
+    return p;
+}
+static void orc_sincos_sum(const orc_angle_parts *A, const orc_angle_parts *T, float rot, float *s, float *c)
+{
+    const double at = A->a + T->a;
+    const double d = (double)rot - at;
+    const double c0 = fma(-A->s, T->s, A->c * T->c);
+    const double s0 = fma(A->c, T->s, A->s * T->c);
+    const double h = -0.5 * (d * d);
+    const double c1 = fma(-d, s0, c0);
+    const double s1 = fma(d, c0, s0);
+    *c = (float)fma(h, c0, c1);
+    *s = (float)fma(h, s0, s1);
+}
+static float orc_lidar_angle(int n) { return (-135.0f + n * .25f) * ORC_PI / 180; } /* LIDAR_ANGLE(n), kernel.cu:42 */
+/* the beams' parts, computed once (they depend on the beam index only) */
+#define ORC_BEAM_TABLE 4096
+static const orc_angle_parts *orc_beam_parts(void)
+{
+    static orc_angle_parts table[ORC_BEAM_TABLE];
+    static volatile int ready = 0;
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    if (!ready) {
+        pthread_mutex_lock(&mu);
+        if (!ready) {
+            for (int n = 0; n < ORC_BEAM_TABLE; n++) table[n] = orc_parts(orc_lidar_angle(n));
+            __sync_synchronize();
+            ready = 1;
+        }
+        pthread_mutex_unlock(&mu);
+    }
+    return table;
+}
+/* with the heading's parts at hand (loops over the beams of one pose) */
+static void orc_clean_lidar_scan_pre(int n, float scan, float theta, const orc_angle_parts *T, float *x, float *y)
+{
+    const float ang = orc_lidar_angle(n);
+    const float rot = ang + theta;
+    orc_angle_parts An;
+    const orc_angle_parts *A;
+    if (n >= 0 && n < ORC_BEAM_TABLE) A = orc_beam_parts() + n;
+    else { An = orc_parts(ang); A = &An; }
     float s, c;
-    orc_sincosf(rot, &s, &c);
+    orc_sincos_sum(A, T, rot, &s, &c);
     *x = scan * c;
     *y = scan * s;
+}
+void orc_clean_lidar_scan(int n, float scan, float theta, float *x, float *y)
+{
+    const orc_angle_parts T = orc_parts(theta);
+    orc_clean_lidar_scan_pre(n, scan, theta, &T, x, y);
 }
 
 /* glm::distance(vec3, vec3) = sqrt(dot(d, d)), dot = (x*x + y*y) + z*z
@@ -451,9 +516,10 @@ static float orc_evaluate_particle_kd(const orc_node *tree, const orc_particle *
                                       int n_beams, uint64_t *nv, uint64_t *nvalid)
 {
     float retv = 0.0f;
+    const orc_angle_parts T = orc_parts(pt->theta);
     for (int j = 0; j < n_beams; j++) {
         float wx, wy;
-        orc_clean_lidar_scan(j, scan[j], pt->theta, &wx, &wy);
+        orc_clean_lidar_scan_pre(j, scan[j], pt->theta, &T, &wx, &wy);
         if (fabsf(wx) < ORC_LIDAR_RANGE && fabsf(wy) < ORC_LIDAR_RANGE) {
             wx += pt->x;
             wy += pt->y;
@@ -1023,9 +1089,10 @@ void orc_score_grid(const int8_t *grid, int dimx, int dimy, const orc_patch *pat
 {
     for (int i = 0; i < n; i++) {
         int retv = 0;
+        const orc_angle_parts T = orc_parts(p[i].theta);
         for (int j = 0; j < n_beams; j++) {
             float wx, wy;
-            orc_clean_lidar_scan(j, scan[j], p[i].theta, &wx, &wy);
+            orc_clean_lidar_scan_pre(j, scan[j], p[i].theta, &T, &wx, &wy);
             wx += p[i].x;
             wy += p[i].y;
             wx = roundf(0.5f * patch->scale_x / patch->res_x + wx / patch->res_x);

@@ -67,6 +67,7 @@ float orc_normal(uint32_t *state, float mean, float stddev);
 
 /* ---- pf_math specification (bit-reproducible transcendentals) ---- */
 void orc_sincosf(float x, float *s, float *c);
+void orc_sincos_d(float x, double *s, double *c); /* the same before the rounding to float */
 double orc_log(double x);
 double orc_ndtri(double y0);
 float orc_erfcinvf(float y);

@@ -34,6 +34,30 @@ def test_kd_create_matches_reference_kdtree_cpp(pkg, oracle, n, seed):
     assert got_product.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("n,seed,span,zmode", [(40000, 1, 300, 0), (65537, 2, 500, 1), (65537, 3, 500, 2), (65537, 4, 500, 3),
+                                               (100003, 5, 800, 0), (50000, 6, 2, 0)])
+def test_kd_create_large_and_tied_levels_match_reference(pkg, oracle, n, seed, span, zmode):
+    """Sizes at which the product's build leaves the plain std::sort call (its sorts run on several threads above 32768 points,
+    csrc/kd_host.cpp), on planar maps (every z level: all keys tied) and not.  zmode 1: two z values (real sorts on the z levels);
+    2: one -0.0 among the zeros (still tied); 3: one odd point."""
+    ref = O.ref_kdtree()
+    if ref is None:
+        pytest.skip("no _ref")
+    pts = grid_points(n, seed, span=span)
+    rng = np.random.RandomState(seed + 100)
+    if zmode == 1:
+        pts[:, 2] = rng.randint(0, 2, n)
+    elif zmode == 2:
+        pts[n // 2, 2] = -0.0
+    elif zmode == 3:
+        pts[n // 3, 2] = 1.0
+    want = np.zeros(n, O.NODE_DTYPE)
+    ref.ref_kd_create(O.P(pts), n, O.P(want))
+    assert pkg.kd_create(pts).tobytes() == want.tobytes()
+    if n <= 65537:
+        assert O.kd_create(pts).tobytes() == want.tobytes()
+
+
 def test_kd_create_3d_points_match_reference(pkg, oracle):
     ref = O.ref_kdtree()
     if ref is None:

@@ -446,8 +446,10 @@ class PfSlam:
 
     def debug_math(self, which, x):
         x = np.ascontiguousarray(x, dtype=np.float32).ravel()
-        out = np.empty(len(x) * (2 if which == 0 else 1), np.float32)
+        out = np.empty(len(x) * (2 if which in (0, 6) else 1), np.float32)
         _chk(self.L.pfslam_debug_math(self._h, which, _p(x), len(x), _p(out)), "pfslam_debug_math")
+        if which == 6:
+            return out.view(np.int32).reshape(-1, 2)
         return out.reshape(-1, 2) if which == 0 else out
 
     # -- read-back

@@ -73,6 +73,10 @@ __device__ __forceinline__ int kd_load_i32(kd_rsrc_t r, int idx)
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, idx << 2, 0, 0);
 }
+__device__ __forceinline__ int kd_load_i32_bytes(kd_rsrc_t r, int byte_offset)
+{
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0);
+}
 // 16 bytes at byte offset `base` + `imm` (imm a compile-time constant: it goes into the instruction's offset field, so several
 // requests off one address cost no address arithmetic)
 __device__ __forceinline__ uint4 kd_load_hot_at(kd_rsrc_t r, int base, int imm)
@@ -86,6 +90,7 @@ struct kd_rsrc_t { const void *base; };
 __device__ kd_rsrc_t kd_rsrc(const void *base);
 __device__ uint4 kd_load_hot(kd_rsrc_t r, int idx);
 __device__ int kd_load_i32(kd_rsrc_t r, int idx);
+__device__ int kd_load_i32_bytes(kd_rsrc_t r, int byte_offset);
 __device__ uint4 kd_load_hot_at(kd_rsrc_t r, int base, int imm);
 #endif
 

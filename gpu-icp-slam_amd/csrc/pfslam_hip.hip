@@ -644,6 +644,12 @@ __global__ void k_debug_math(int which, const float *__restrict__ in, int n, flo
         out[i] = pf::fsqrt(in[i]);
     } else if (which == 5) {
         out[i] = pf::fdiv(in[i], 0.025f);
+    } else if (which == 6) { // the score kernel's sub-cell index: exact, and the shortcut (INT_MIN where it does not apply)
+        const float res = 0.025f, inv = pf::fdiv(1.0f, res);
+        float clear;
+        const int fast = sub_index_fast(in[i], 2.0f * inv, clear);
+        out[2 * i] = __int_as_float(sub_index(in[i], res, inv));
+        out[2 * i + 1] = __int_as_float(clear > 0.0f ? fast : (int)0x80000000);
     }
 }
 
@@ -1723,7 +1729,7 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
     if (!h || !in_host || !out_host || n <= 0) return fail("pfslam_debug_math: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(settle(h));
-    const int per = which == 0 ? 2 : 1;
+    const int per = which == 0 || which == 6 ? 2 : 1;
     float *d_in = nullptr, *d_out = nullptr;
     CHK(dalloc(&d_in, (size_t)n));
     CHK(dalloc(&d_out, (size_t)n * per));

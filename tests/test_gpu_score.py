@@ -40,6 +40,40 @@ def test_device_math_matches_oracle_bitwise(gpu):
     h.close()
 
 
+def test_sub_cell_index_shortcut_agrees_with_the_exact_index(gpu):
+    """The score kernel takes a query's sub-cell index from floor(q * 2 / res) unless q is within a margin of a sub-cell edge
+    (csrc/kd_cells.hip.inc, sub_index_fast); the exact index compares with the float edges fl(k res) and fl(fl(k res) + res / 2).
+    Both are evaluated on the device here, a few ulps either side of EVERY edge within +-105 m and on random points, and the
+    exact one is re-derived in numpy from the sorted edge list."""
+    h = gpu.PfSlam(64)
+    res = np.float32(0.025)
+    k = np.arange(-4200, 4201)
+    lo = k.astype(np.float32) * res
+    mid = lo + np.float32(0.5) * res
+    edges = np.empty(2 * len(k), np.float32)      # edge of sub-cell S = 2 k and S = 2 k + 1
+    edges[0::2], edges[1::2] = lo, mid
+    assert (np.diff(edges) > 0).all()
+    # +-40 ulps around every edge
+    near = [edges]
+    a = b = edges
+    for _ in range(40):
+        a = np.nextafter(a, np.float32(np.inf)); b = np.nextafter(b, np.float32(-np.inf))
+        near += [a, b]
+    rng = np.random.RandomState(3)
+    rnd = rng.uniform(-104.9, 104.9, 1000000).astype(np.float32)
+    q = np.concatenate(near + [rnd]).astype(np.float32)
+    got = h.debug_math(6, q)
+    want = np.searchsorted(edges, q, side="right") - 1 + 2 * int(k[0])   # max S with edge(S) <= q
+    inside = (q >= edges[0]) & (q < edges[-1])
+    assert (got[inside, 0] == want[inside]).all()
+    safe = got[:, 1] != np.int32(-2 ** 31)
+    assert (got[safe, 1] == got[safe, 0]).all()
+    assert not safe[: len(edges)].any()                      # a query ON an edge is never taken by the shortcut
+    unsafe_rnd = 1.0 - safe[-len(rnd):].mean()
+    assert unsafe_rnd < 5e-3, unsafe_rnd                      # ... and almost every other query is
+    h.close()
+
+
 def test_traversal_matches_oracle_including_root_parent_case(gpu, small_world):
     tree = small_world["tree"]
     h = gpu.PfSlam(64)

@@ -192,6 +192,7 @@ struct pfslam_handle {
     size_t plan_rows = 0;
     bool plan_valid = false; // the last scoring pass made a plan
     pf::KdGroupBox *group_box = nullptr;
+    pf::AngleParts *group_parts = nullptr; // cos / sin of every group's centre heading (k_group_box -> k_cells_mark)
     // lattice-cell rows (kd_cells.hip.inc)
     bool lattice_ok = false;   // planar map, every node on the lattice k * res of the config (all maps the SLAM step builds are)
     bool cells_valid = false;  // the last scoring pass used cell rows
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
 // ---- shared-prefix plan (kd_device.h "Shared-prefix plan"): round 2; still used for planar maps that are not on the lattice -----
 // pose bounding box of every group of 64 lanes (= one wave of the score kernel)
 __global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, const float *__restrict__ py, const float *__restrict__ pth,
-                                                  int n, const int *__restrict__ order, pf::KdGroupBox *__restrict__ box)
+                                                  int n, const int *__restrict__ order, pf::KdGroupBox *__restrict__ box,
+                                                  pf::AngleParts *__restrict__ parts)
 {
     const int slot = blockIdx.x * 64 + threadIdx.x;
     const bool in = slot < n;
@@ -306,6 +308,8 @@ __global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, 
         pf::KdGroupBox b{xlo, xhi, ylo, yhi, tlo, thi, min(64, n - (int)blockIdx.x * 64), 0};
         if (bad != 0ull) b.xlo = b.xhi = NAN;
         box[blockIdx.x] = b;
+        if (parts) parts[blockIdx.x] = pf::angle_parts(0.5f * (b.tlo + b.thi)); // of beam_box's centre heading: once per group here
+
     }
 }
 
@@ -867,6 +871,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->census_store) (void)hipFree(h->census_store);
     if (h->plan) (void)hipFree(h->plan);
     if (h->group_box) (void)hipFree(h->group_box);
+    if (h->group_parts) (void)hipFree(h->group_parts);
     if (h->cell_tab) (void)hipFree(h->cell_tab);
     if (h->cell_list) (void)hipFree(h->cell_list);
     if (h->cell_state) (void)hipFree(h->cell_state);
@@ -1351,6 +1356,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     if (use_plan || use_cells) { // the pose boxes do not need the map: in front of the join
         const int groups = (h->n + 63) / 64;
         if (!h->group_box) CHK(dalloc(&h->group_box, (size_t)groups)); // n is fixed for the handle's lifetime
+        if (!h->group_parts) CHK(dalloc(&h->group_parts, (size_t)groups));
         const size_t rows = (size_t)groups * h->nb;
         if (use_plan && rows > h->plan_rows) {
             if (h->plan) HIPCHK(hipFree(h->plan));
@@ -1358,7 +1364,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             CHK(dalloc(&h->plan, rows));
             h->plan_rows = rows;
         }
-        hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box);
+        hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box, h->group_parts);
     }
     hipEvent_t t_a = nullptr, t_b = nullptr;
     if (h->timing && !census) {
@@ -1369,7 +1375,8 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     if (use_cells) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
         const int groups = (h->n + 63) / 64, per_block = PF_MARK_THREADS * PF_MARK_GROUPS;
         hipLaunchKernelGGL(k_cells_mark, dim3(h->nb, (groups + per_block - 1) / per_block), dim3(PF_MARK_THREADS), 0, h->stream,
-                           (const pf::KdGroupBox *)h->group_box, groups, (const float *)h->scan, h->nb, geo, h->cell_tab, h->cell_list, h->cell_state);
+                           (const pf::KdGroupBox *)h->group_box, groups, (const float *)h->scan, h->nb, geo, h->cell_tab, h->cell_list, h->cell_state,
+                           (const pf::AngleParts *)h->group_parts, (const pf::BeamParts *)h->beam_angle);
     }
     CHK(join_map(h)); // from here on the scoring pass reads the map (lane order, pose boxes and cell marking above did not)
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four

@@ -109,4 +109,6 @@ def test_roofline_census_agrees_with_committed_pmc():
     pm = json.load(open(os.path.join(ROOT, p["source"])))
     frac_pmc = pm["avg_per_launch"]["TA_BUFFER_READ_WAVEFRONTS_sum"] * 1024.0 / (pm["kernel_ms"] * 1e-3) / 1e9 / r["peak"]
     assert abs(frac_pmc / r["frac_all_gathers_as_16B"] - 1.0) < 0.05, (frac_pmc, r["frac_all_gathers_as_16B"])
-    assert r["frac"] <= r["frac_all_gathers_as_16B"] <= 1.25 * r["frac"]   # the 4-byte gathers (cell-table words, parent indices) priced as 16-byte ones
+    # the 4-byte gathers (cell-table words, parent indices) priced as 16-byte ones: a third of all wave gathers once the corner test
+    # has left most rows with a single 16-byte slot
+    assert r["frac"] <= r["frac_all_gathers_as_16B"] <= 1.6 * r["frac"]

@@ -490,10 +490,11 @@ def main():
                         "launches of that process (dispatches [warmup, warmup + steps) of the timed instantiation).  ta_busy = TA_TA_BUSY_sum / CUs / (GRBM_GUI_ACTIVE / 8 XCDs); "
                         "ta_cycles_frac = TA_BUFFER_TOTAL_CYCLES_sum / CUs / kernel cycles; hbm = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 "
                         "correction of MI355X_MICROARCH.md) -- the map records are cache resident, compulsory HBM traffic is ~20 B per "
-                        "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement); "
+                        "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement; the census "
+                        "also counts the parent-index reads of the generic tail, global loads a BUFFER counter does not see); "
                         "valu_issue_frac = 4 cycles x VALU wave-instructions per SIMD / kernel cycles: the share of its issue cycles "
-                        "a SIMD spends on vector ALU instructions of this kernel (the cell-row kernel is bound by THIS, not by the "
-                        "gather path: see DESIGN.md section 4)"},
+                        "a SIMD spends on vector ALU instructions of this kernel (the cell-row kernel runs with this and ta_busy both "
+                        "at 0.8-0.9: see DESIGN.md section 4)"},
             "alg_equiv": {"bytes_per_eval": alg_bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                           "GBs": alg_bytes_per_eval * n_local / kern_s / 1e9,
                           "note": "SURVEY 8d's algorithmic node bytes (B_valid x V x 32 B + 20 B): served from L1/L2, "

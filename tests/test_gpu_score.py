@@ -136,6 +136,66 @@ def test_score_kd_edge_scans(gpu, small_world):
     h.close()
 
 
+def test_score_queries_exactly_on_cell_edges(gpu, small_world):
+    """The rows of the scan-match kernel are built for a sub-cell WITHOUT its edges (corner test, csrc/kd_cells.hip.inc): a query
+    exactly on a low edge must take the generic traversal.  Beam 540 looks along the heading (LIDAR_ANGLE(540) = 0), so with
+    theta = 0 its end point is (x + r, y) EXACTLY: particles sit on lattice edges, on sub-cell edges and one float either side of
+    them, and the beam's range is a lattice multiple, so that x + r lands on edges too."""
+    tree = small_world["tree"]
+    res = np.float32(0.025)
+    k = np.arange(-30, 31)
+    lo = k.astype(np.float32) * res
+    edges = np.concatenate([lo, lo + np.float32(0.5) * res])
+    vals = np.concatenate([edges, np.nextafter(edges, np.float32(np.inf)), np.nextafter(edges, np.float32(-np.inf))])
+    rng = np.random.RandomState(5)
+    n = 6000
+    p = O.make_particles(n, 0.0, 0.0, 0.0)
+    p["y"] = vals[rng.randint(0, len(vals), n)]
+    p["x"] = vals[rng.randint(0, len(vals), n)]
+    p["theta"] = np.where(rng.rand(n) < 0.8, np.float32(0.0), rng.uniform(-0.01, 0.01, n).astype(np.float32))
+    h = gpu.PfSlam(n)
+    h.set_map(tree)
+    h.set_particles(p)
+    h.set_variant(3)  # the organised kernel whatever the particle count
+    for r540 in (np.float32(80) * res, np.float32(123) * res + np.float32(0.5) * res, np.float32(2.0)):
+        scan = small_world["scan"].copy()
+        scan[540] = r540
+        scan[538:543:2] = r540  # neighbours: almost on the edges
+        h.set_scan(scan)
+        assert (bits(h.score_kd()) == bits(O.score_kd(tree, p, scan))).all()
+    st = h.cell_stats()
+    assert st["rows"] > 0
+    h.close()
+    # A wall along x with a different weight on every point: beam 540 of a particle at (0, y), theta = 0, ends at (r, y) exactly, and
+    # r = fl(fl(k res) + res / 2) is the edge between two sub-cells AND the bisector of the wall points k and k + 1 -- the one place
+    # where the row of the sub-cell [mid, ...) (which holds k + 1 only) would give the wrong node when k wins the tie.
+    kk = np.arange(0, 400)
+    wall = np.zeros((len(kk), 4), np.float32)
+    wall[:, 0] = kk.astype(np.float32) * res
+    wall[:, 3] = (kk % 200) - 100
+    rng.shuffle(wall)
+    wtree = gpu.kd_create(wall)
+    n = 4800
+    q = O.make_particles(n, 0.0, 0.0, 0.0)
+    ys = np.array([0.0, 0.0125, -0.0125, 0.025, 1e-9, -1e-9, 0.006, -0.02], np.float32)
+    q["y"] = ys[np.arange(n) % len(ys)]
+    q["x"] = np.float32(0.0)
+    q["theta"] = np.float32(0.0)
+    h = gpu.PfSlam(n)
+    h.set_map(wtree)
+    h.set_particles(q)
+    h.set_variant(3)
+    base = np.full(1081, 1000.0, np.float32)  # every other beam out of range: the fit IS the weight of beam 540's nearest node
+    for kq in range(3, 390, 7):
+        lo_k = np.float32(kq) * res
+        for r540 in (lo_k + np.float32(0.5) * res, lo_k, np.nextafter(lo_k + np.float32(0.5) * res, np.float32(0))):
+            scan = base.copy()
+            scan[540] = r540
+            h.set_scan(scan)
+            assert (bits(h.score_kd()) == bits(O.score_kd(wtree, q, scan))).all(), (kq, float(r540))
+    h.close()
+
+
 def test_score_kd_after_inserts_unbalanced_tree(gpu, small_world):
     """Leaf-appended nodes (KDTree::InsertNode) break the pre-order 'left = i+1' pattern."""
     base = small_world["tree"]

@@ -188,7 +188,9 @@ def test_score_queries_exactly_on_cell_edges(gpu, small_world):
     base = np.full(1081, 1000.0, np.float32)  # every other beam out of range: the fit IS the weight of beam 540's nearest node
     for kq in range(3, 390, 7):
         lo_k = np.float32(kq) * res
-        for r540 in (lo_k + np.float32(0.5) * res, lo_k, np.nextafter(lo_k + np.float32(0.5) * res, np.float32(0))):
+        mid_k = lo_k + np.float32(0.5) * res
+        # on the bisector, on a wall point, and ONE float either side of the bisector: the corners [lo+, hi-] of the corner test
+        for r540 in (mid_k, lo_k, np.nextafter(mid_k, np.float32(0)), np.nextafter(mid_k, np.float32(np.inf)), np.nextafter(lo_k, np.float32(np.inf))):
             scan = base.copy()
             scan[540] = r540
             h.set_scan(scan)

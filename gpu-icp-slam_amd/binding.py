@@ -386,10 +386,11 @@ class PfSlam:
         return dict(zip(keys, [float(v) for v in out]))
 
     def cell_stats(self):
-        """Lattice-cell rows of the last scoring pass (all zero when it did not use them)."""
-        out = (C.c_double * 8)()
+        """The persistent lattice-cell rows (all zero when the last scoring pass did not use them)."""
+        out = (C.c_double * 16)()
         _chk(self.L.pfslam_cell_stats(self._h, out), "pfslam_cell_stats")
-        keys = ("cells", "rows", "candidates", "redescent_candidates", "cells_without_row", "pool_slots", "window_kx", "window_ky")
+        keys = ("cells", "rows", "candidates", "redescent_candidates", "cells_without_row", "pool_slots", "window_kx", "window_ky",
+                "walked_from_root", "extended", "reused", "claimed", "flags", "records_walked", "wipes")
         return dict(zip(keys, [float(v) for v in out]))
 
     def ubench_gather(self):

@@ -197,8 +197,17 @@ struct pfslam_handle {
     bool lattice_ok = false;   // planar map, every node on the lattice k * res of the config (all maps the SLAM step builds are)
     bool cells_valid = false;  // the last scoring pass used cell rows
     unsigned *cell_tab = nullptr;
-    int *cell_list = nullptr, *cell_state = nullptr;
+    int *cell_list = nullptr, *cell_state = nullptr, *cell_rec = nullptr;
     uint4 *cell_pool = nullptr;
+    // the rows persist across frames (kd_cells.hip.inc): wiped when the map is replaced (set_map, re-balance) or the device asks for
+    // it in a frame's header (list / pool exhausted, cloud far from the window centre)
+    bool cells_wipe_pending = false;
+    int cells_wipe_seq = 0;       // header flags of frames with an older ticket predate the last wipe
+    bool cells_async = false;     // frame loops: new cells are found and walked on the aux stream, under the scan-match kernel
+    long cells_wipes = 0;         // statistics
+    hipEvent_t ev_boxes = nullptr; // the pose boxes of the pass are ready (main stream -> aux stream)
+    hipEvent_t ev_marked = nullptr; // ... and the aux stream's marking pass has read them (aux -> main, before the next pass's boxes)
+    bool mark_on_aux = false;
     pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
 };
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     out[(size_t)blockIdx.y * n + (direct ? i : slot)] = acc;
 }
 
-#include "kd_cells.hip.inc" // round 3: lattice-cell rows (k_cells_mark, k_cell_rows, k_score_kd_cells); beam_box is shared with k_plan
+#include "kd_cells.hip.inc" // lattice-cell rows (k_cells_mark, k_cells_update, k_score_kd_cells); beam_box is shared with k_plan
 
 // ---- shared-prefix plan (kd_device.h "Shared-prefix plan"): round 2; still used for planar maps that are not on the lattice -----
 // pose bounding box of every group of 64 lanes (= one wave of the score kernel)
@@ -513,8 +522,8 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
 }
 // reach: metres per radian -- a heading difference d moves a beam end point by ~ reach * d, so one cell is equally wide in x, y
 // and reach * theta (what makes the 64 queries of a wave a small box, see the shared-prefix plan)
-// cs != nullptr (lattice-cell rows, kd_cells.hip.inc): block 0 also resets the pass's cell counters and puts the window of the
-// cell table around the cloud's mean
+// cs != nullptr (lattice-cell rows, kd_cells.hip.inc): block 0 also puts the window of the cell table around the cloud's mean when the
+// table has just been wiped, and reports a cloud that has drifted away from the window's middle
 __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x, const float *__restrict__ y,
                                                     const float *__restrict__ th, int n, float reach, int bits,
                                                     unsigned *__restrict__ cell, int *__restrict__ hist, int *__restrict__ cs, CellGeom geo)
@@ -526,11 +535,16 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     const float inv = 1.0f / (float)ns;
     const float mx = block_sum_256(sx, red) * inv, my = block_sum_256(sy, red) * inv, mt = block_sum_256(st, red) * inv;
     if (cs && blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int k = 0; k < 8; k++) cs[k] = 0;
         const bool fin = fabsf(mx) < 1e6f && fabsf(my) < 1e6f; // NaN poses among the first slots: any window will do
-        // in sub-cell units, on a whole cell (even)
-        cs[2] = PF_CELL_SUB * (fin ? lattice_floor(mx, geo.resx, geo.invx) : 0) - PF_CELL_WIN / 2;
-        cs[3] = PF_CELL_SUB * (fin ? lattice_floor(my, geo.resy, geo.invy) : 0) - PF_CELL_WIN / 2;
+        const int kx = fin ? lattice_floor(mx, geo.resx, geo.invx) : 0, ky = fin ? lattice_floor(my, geo.resy, geo.invy) : 0;
+        if (cs[PF_CS_FLAGS] & PF_CF_NEED_ORIGIN) { // first pass after a wipe: in sub-cell units, on a whole cell (even)
+            cs[PF_CS_OX] = PF_CELL_SUB * kx - PF_CELL_WIN / 2;
+            cs[PF_CS_OY] = PF_CELL_SUB * ky - PF_CELL_WIN / 2;
+            atomicAnd(&cs[PF_CS_FLAGS], ~PF_CF_NEED_ORIGIN);
+        } else if (fin) { // the window stays where it is while the rows persist; the host is told when the cloud leaves its middle
+            const int dx = kx - (cs[PF_CS_OX] + PF_CELL_WIN / 2) / PF_CELL_SUB, dy = ky - (cs[PF_CS_OY] + PF_CELL_WIN / 2) / PF_CELL_SUB;
+            if (abs(dx) > PF_CELL_DRIFT_MAX || abs(dy) > PF_CELL_DRIFT_MAX) atomicOr(&cs[PF_CS_FLAGS], PF_CF_FAR);
+        }
     }
     float vx = 0, vy = 0, vt = 0;
     for (int k = threadIdx.x; k < ns; k += 256) {
@@ -876,6 +890,9 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->cell_list) (void)hipFree(h->cell_list);
     if (h->cell_state) (void)hipFree(h->cell_state);
     if (h->cell_pool) (void)hipFree(h->cell_pool);
+    if (h->cell_rec) (void)hipFree(h->cell_rec);
+    if (h->ev_boxes) (void)hipEventDestroy(h->ev_boxes);
+    if (h->ev_marked) (void)hipEventDestroy(h->ev_marked);
     if (h->beam_angle) (void)hipFree(h->beam_angle);
     if (h->fit_acc) (void)hipFree(h->fit_acc);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1006,6 +1023,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
         h->kd_size = 0;
         h->mirror_n = 0;
         h->mirror_stale = false;
+        h->cells_wipe_pending = true;
         HIPCHK(hipMemsetAsync(h->kd_state, 0, 16, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         return 0;
@@ -1069,6 +1087,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     h->planar = planar;
     h->integral_w = integral;
     h->lattice_ok = lattice;
+    h->cells_wipe_pending = true; // rows of the previous map
     return 0;
 }
 
@@ -1281,10 +1300,40 @@ static int score_chunks(const pfslam_handle *h)
     return chunks;
 }
 
+// ---- persistent lattice-cell rows: host side ---------------------------------------------------------------------------------
+#define PF_CELLS_GRID 2048 /* workgroups (one wave each) of k_cells_update: grid-stride over the records */
+struct CellArgs { unsigned *tab; int *list, *cs; uint4 *pool; int *rec; };
+__global__ void k_cells_reset(int *cs)
+{
+    if (threadIdx.x < PF_CS_WORDS) cs[threadIdx.x] = threadIdx.x == PF_CS_FLAGS ? PF_CF_NEED_ORIGIN : 0;
+}
+// table, records and pool start over (enqueued; the caller has joined the aux stream).  105 MB of memset: rare -- a new map, a
+// re-balance (an 11 ms stall of its own), an exhausted list / pool, a cloud that has left the middle of the window.
+static int cells_wipe(pfslam_handle *h)
+{
+    HIPCHK(hipMemsetAsync(h->cell_tab, 0, (size_t)PF_CELL_WIN * PF_CELL_WIN * 4, h->stream));
+    hipLaunchKernelGGL(k_cells_reset, dim3(1), dim3(64), 0, h->stream, h->cell_state);
+    HIPCHK(hipGetLastError());
+    h->cells_wipe_pending = false;
+    h->cells_wipe_seq = h->seq;
+    h->cells_wipes++;
+    return 0;
+}
+// behind every insert into the tree (k_test_new), on the stream that ran it: the records' links are looked at, the cells that gained
+// a node are extended, their rows and those of the cells walked under the scan-match kernel are published
+static int launch_cells_update(pfslam_handle *h, hipStream_t st)
+{
+    if (!h->cell_tab || h->cells_wipe_pending) return 0; // (a pending wipe: the records belong to a map that is gone)
+    const CellGeom geo{h->cfg.map_res_x, h->cfg.map_res_y, 1.0f / h->cfg.map_res_x, 1.0f / h->cfg.map_res_y};
+    hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,
+                       h->cell_pool, h->cell_rec);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 struct ShardPack;
 __global__ void k_reduce_partials_minmax(float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
-                                         const float *x, const float *y, const float *th, ShardPack *pack, int wipe, unsigned *cell_tab,
-                                         const int *cell_list, int *cell_state);
+                                         const float *x, const float *y, const float *th, ShardPack *pack, int wipe);
 __global__ void k_shard_pack(const long long *stats, const float *x, const float *y, const float *th, int n, int goff, ShardPack *pack);
 __global__ void k_reduce_partials_minmax_wide(const float *partial, int n, int chunks, const int *order, float *fit, long long *stats);
 template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
@@ -1325,12 +1374,23 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     if (use_cells && !h->cell_tab) {
         CHK(dalloc(&h->cell_tab, (size_t)PF_CELL_WIN * PF_CELL_WIN));
         CHK(dalloc(&h->cell_list, (size_t)PF_CELL_LIST_CAP));
-        CHK(dalloc(&h->cell_state, 16));
+        CHK(dalloc(&h->cell_state, PF_CS_WORDS));
+        CHK(dalloc(&h->cell_rec, (size_t)PF_CELL_LIST_CAP * PF_REC_WORDS));
         CHK(dalloc(&h->cell_pool, (size_t)PF_CELL_POOL_CAP + PF_ROW_SLACK));
         CHK(dalloc(&h->fit_acc, (size_t)h->n));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_boxes, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_marked, hipEventDisableTiming));
         HIPCHK(hipMemsetAsync(h->fit_acc, 0, (size_t)h->n * 4, h->stream));
-        HIPCHK(hipMemsetAsync(h->cell_tab, 0, (size_t)PF_CELL_WIN * PF_CELL_WIN * 4, h->stream));
-        HIPCHK(hipMemsetAsync(h->cell_state, 0, 64, h->stream));
+        h->cells_wipe_pending = true;
+    }
+    // The rows persist (kd_cells.hip.inc).  Synchronous pass: new cells are marked, walked and published in front of the scan-match
+    // kernel, on this stream (stage-level calls, the first pass after a wipe, per-phase timing).  Asynchronous pass (frame loops):
+    // marking and the walk of the new cells run on the aux stream UNDER the scan-match kernel, whose lanes take the generic traversal
+    // in a cell that has no rows yet; k_cells_update publishes them behind the frame's insert (launch_map_update_device).
+    const bool cells_sync = use_cells && (!h->cells_async || h->cells_wipe_pending || census != nullptr || h->census_log != nullptr);
+    if (use_cells && h->cells_wipe_pending) {
+        CHK(join_map(h)); // the previous frame's k_cells_update is the table's last writer
+        CHK(cells_wipe(h));
     }
     // default: counting sort over Hilbert cells of the cloud (3 launches), 2^18 cells up to 400 k particles, 2^21 above
     static const float theta_weight = getenv("PFSLAM_THETA_WEIGHT") ? (float)atof(getenv("PFSLAM_THETA_WEIGHT")) : 1.0f;
@@ -1364,6 +1424,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             CHK(dalloc(&h->plan, rows));
             h->plan_rows = rows;
         }
+        if (h->mark_on_aux) { // the previous frame's marking pass (aux stream, long finished) read the boxes this launch overwrites
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_marked, 0));
+            h->mark_on_aux = false;
+        }
         hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box, h->group_parts);
     }
     hipEvent_t t_a = nullptr, t_b = nullptr;
@@ -1372,11 +1436,24 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         CHK(timer_event(h, &t_b));
         HIPCHK(hipEventRecord(t_a, h->stream));
     }
+    const CellArgs ca{h->cell_tab, h->cell_list, h->cell_state, h->cell_pool, h->cell_rec};
     if (use_cells) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
+        hipStream_t st = h->stream;
+        if (!cells_sync) { // behind whatever the aux stream still has to do for the previous frame (its map update, this frame's ICP)
+            HIPCHK(hipEventRecord(h->ev_boxes, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->aux, h->ev_boxes, 0));
+            st = h->aux;
+        }
         const int groups = (h->n + 63) / 64, per_block = PF_MARK_THREADS * PF_MARK_GROUPS;
-        hipLaunchKernelGGL(k_cells_mark, dim3(h->nb, (groups + per_block - 1) / per_block), dim3(PF_MARK_THREADS), 0, h->stream,
+        hipLaunchKernelGGL(k_cells_mark, dim3(h->nb, (groups + per_block - 1) / per_block), dim3(PF_MARK_THREADS), 0, st,
                            (const pf::KdGroupBox *)h->group_box, groups, (const float *)h->scan, h->nb, geo, h->cell_tab, h->cell_list, h->cell_state,
                            (const pf::AngleParts *)h->group_parts, (const pf::BeamParts *)h->beam_angle);
+        if (!cells_sync) { // the new cells' walks from the root: records only, published behind this frame's insert
+            HIPCHK(hipEventRecord(h->ev_marked, st));
+            h->mark_on_aux = true;
+            hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec);
+        }
+        HIPCHK(hipGetLastError());
     }
     CHK(join_map(h)); // from here on the scoring pass reads the map (lane order, pose boxes and cell marking above did not)
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
@@ -1413,9 +1490,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     };
     if (use_plan || use_cells) {
         const int groups = (h->n + 63) / 64;
-        if (use_cells) { // one row per marked cell
-            hipLaunchKernelGGL(k_cell_rows, dim3(2048), dim3(64), 0, h->stream, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list,
-                               h->cell_state, h->cell_pool);
+        if (use_cells) { // rows of the new cells (and a look at every record's links)
+            if (cells_sync)
+                hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, h->stream, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec);
         } else
             hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                                (const float *)h->scan, h->nb, kd_view(h), h->plan);
@@ -1438,12 +1515,6 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         scan_match(h->census_log + h->census_n++);
         HIPCHK(hipGetLastError());
     }
-    // wipe the pass's cells (the table is all zero between passes): the frame loops' reduce kernel does it on the way
-    const bool clear_in_reduce = use_cells && used > 1 && fuse_minmax && !(used >= 256 && !shard_pack && h->goff == 0 && !acc_out);
-    if (use_cells && !clear_in_reduce) {
-        hipLaunchKernelGGL(k_cells_clear, dim3(128), dim3(256), 0, h->stream, h->cell_tab, (const int *)h->cell_list, h->cell_state);
-        HIPCHK(hipGetLastError());
-    }
     if (fuse_minmax) {
         if (h->icp_forked) CHK(join_icp(h)); // the aux stream reset the keys
         if (!h->stats_clean) CHK(launch_stats_reset(h, h->stream));
@@ -1456,8 +1527,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     } else if (used > 1 && fuse_minmax) {
         hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
                            acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th,
-                           shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0,
-                           clear_in_reduce ? h->cell_tab : (unsigned *)nullptr, (const int *)h->cell_list, h->cell_state);
+                           shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0);
         HIPCHK(hipGetLastError());
     } else {
         if (used > 1) {
@@ -1614,28 +1684,35 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
     return 0;
 }
 
-// the lattice-cell rows of the LAST scoring pass: out[0] lattice cells marked, [1] rows built (one per sub-cell: four per marked cell), [2] mean first-descent candidates per row,
-// [3] mean re-descent candidates per row, [4] sub-cells left without a row (too many candidates / pool exhausted: generic lanes),
-// [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell.  All zero when the pass did not use cell rows.
-extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[8])
+// the persistent lattice-cell rows: out[0] cells claimed since the last wipe (one record each), [1] live rows (one per sub-cell: up to four
+// per cell), [2] mean first-descent candidates per row, [3] mean re-descent candidates per row, [4] sub-cells without a row (too many
+// candidates / pool exhausted: generic lanes), [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell,
+// [8 .. 11] the last finished update: cells walked from the root / extended because a link gained a node / looked at and reused
+// as they were / newly claimed by the marking pass, [12] device flags (PF_CF_*: 1 list full, 2 pool full, 8 cloud far from the window
+// centre), [13] records walked, [14] wipes so far (host), [15] 0.  All zero when the last scoring pass did not use cell rows.
+extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
 {
     if (!h || !out) return fail("pfslam_cell_stats: bad argument");
-    for (int k = 0; k < 8; k++) out[k] = 0.0;
+    for (int k = 0; k < 16; k++) out[k] = 0.0;
     if (!h->cell_state || !h->cells_valid) return 0;
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(settle(h));
-    int cs[16];
+    int cs[PF_CS_WORDS];
     HIPCHK(hipMemcpyAsync(cs, h->cell_state, sizeof(cs), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const int *last = cs + 8; // k_cells_clear's copy of the finished pass
-    out[0] = last[0];
-    out[1] = last[4];
-    out[2] = last[4] ? (double)last[5] / last[4] : 0.0;
-    out[3] = last[4] ? (double)last[6] / last[4] : 0.0;
-    out[4] = last[7];
-    out[5] = last[1];
-    out[6] = last[2];
-    out[7] = last[3];
+    const int rows = cs[PF_CS_ROWS];
+    out[0] = std::min(cs[PF_CS_COUNT], PF_CELL_LIST_CAP);
+    out[1] = rows;
+    out[2] = rows ? (double)cs[PF_CS_N1] / rows : 0.0;
+    out[3] = rows ? (double)cs[PF_CS_N2] / rows : 0.0;
+    out[4] = cs[PF_CS_NONE];
+    out[5] = cs[PF_CS_POOL];
+    out[6] = cs[PF_CS_OX];
+    out[7] = cs[PF_CS_OY];
+    for (int k = 0; k < 4; k++) out[8 + k] = cs[PF_CS_LAST_FRESH + k];
+    out[12] = cs[PF_CS_FLAGS];
+    out[13] = cs[PF_CS_DONE];
+    out[14] = (double)h->cells_wipes;
     return 0;
 }
 

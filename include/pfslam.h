@@ -271,10 +271,13 @@ int pfslam_ubench_gather(pfslam_handle *h, double out[4]);
  * [4] fraction without a plan, [5] fraction with a full candidate list, [6..8] mean extent of a wave's pose box in x, y (m) and
  * heading (rad), [9] waves.  All zero when no plan was made (non-planar map, few particles, variant 2). */
 int pfslam_plan_stats(pfslam_handle *h, double out[10]);
-/* the lattice-cell rows of the LAST scoring pass (csrc/kd_cells.hip.inc): out[0] lattice cells marked, [1] rows built (one per sub-cell: four per marked cell), [2] mean
- * first-descent candidates per row, [3] mean re-descent candidates per row, [4] sub-cells left without a row, [5] 16-byte
- * pool slots used, [6] [7] lattice index of the window's corner cell.  All zero when the pass did not use cell rows. */
-int pfslam_cell_stats(pfslam_handle *h, double out[8]);
+/* the persistent lattice-cell rows (csrc/kd_cells.hip.inc): out[0] lattice cells claimed since the last wipe, [1] live rows (one per
+ * sub-cell: up to four per cell), [2] mean first-descent candidates per row, [3] mean re-descent candidates per row, [4] sub-cells
+ * without a row, [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell, [8 .. 11] the last finished update:
+ * cells walked from the root / extended because one of their links gained a node / looked at and reused as they were / newly
+ * claimed, [12] device flags (1 list full, 2 pool full, 8 cloud far from the window centre), [13] records walked, [14] wipes so
+ * far, [15] 0.  All zero when the last scoring pass did not use cell rows. */
+int pfslam_cell_stats(pfslam_handle *h, double out[16]);
 int pfslam_set_variant(pfslam_handle *h, int variant);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */

@@ -198,6 +198,7 @@ struct pfslam_handle {
     bool cells_valid = false;  // the last scoring pass used cell rows
     unsigned *cell_tab = nullptr;
     int *cell_list = nullptr, *cell_state = nullptr, *cell_rec = nullptr;
+    int *cell_touched = nullptr; // [0] count, then the links that gained a node in the last k_test_new
     uint4 *cell_pool = nullptr;
     // the rows persist across frames (kd_cells.hip.inc): wiped when the map is replaced (set_map, re-balance) or the device asks for
     // it in a frame's header (list / pool exhausted, cloud far from the window centre)
@@ -205,9 +206,17 @@ struct pfslam_handle {
     int cells_wipe_seq = 0;       // header flags of frames with an older ticket predate the last wipe
     bool cells_async = false;     // frame loops: new cells are found and walked on the aux stream, under the scan-match kernel
     long cells_wipes = 0;         // statistics
+    long cells_passes = 0;        // publishing updates since the last wipe
+    int cells_gen = 0;            // wipe generation: a record written in an earlier one counts as not written
     hipEvent_t ev_boxes = nullptr; // the pose boxes of the pass are ready (main stream -> aux stream)
-    hipEvent_t ev_marked = nullptr; // ... and the aux stream's marking pass has read them (aux -> main, before the next pass's boxes)
+    hipEvent_t ev_marked = nullptr; // ... and the cell stream's marking pass has read them (-> main, before the next pass's boxes)
     bool mark_on_aux = false;
+    hipStream_t istream = nullptr;  // the ICP solve: behind the previous frame's insert (ev_tree), beside its k_cells_update, in front of the scan-match kernel
+    hipEvent_t ev_tree = nullptr;
+    bool tree_event = false;
+    hipStream_t cstream = nullptr;  // marking + walks of the new cells in the frame loops: beside the ICP solve, under the scan-match kernel
+    hipEvent_t ev_walked = nullptr; // ... finished: the frame's insert (k_test_new changes the tree they read) waits for it
+    bool walk_pending = false;
     pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
 };
@@ -729,7 +738,17 @@ static int create_impl(pfslam_handle *h)
     h->own_stream = true;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
-    HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    {
+        // the aux streams carry short dependent chains that run BESIDE the scan-match kernel's 131 k single-wave workgroups: at normal
+        // priority their workgroups queue behind that flood (the one-workgroup ICP solve: 33 -> 284 us)
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        static const bool prio = !(getenv("PFSLAM_AUX_PRIO") && atoi(getenv("PFSLAM_AUX_PRIO")) == 0);
+        HIPCHK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio ? hi : lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, prio ? hi : lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming));
+    }
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_mapfork, hipEventDisableTiming));
@@ -873,6 +892,10 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->istream) { (void)hipStreamSynchronize(h->istream); (void)hipStreamDestroy(h->istream); }
+    if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
+    if (h->ev_walked) (void)hipEventDestroy(h->ev_walked);
     if (h->topo_stream) { (void)hipStreamSynchronize(h->topo_stream); (void)hipStreamDestroy(h->topo_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -891,6 +914,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->cell_state) (void)hipFree(h->cell_state);
     if (h->cell_pool) (void)hipFree(h->cell_pool);
     if (h->cell_rec) (void)hipFree(h->cell_rec);
+    if (h->cell_touched) (void)hipFree(h->cell_touched);
     if (h->ev_boxes) (void)hipEventDestroy(h->ev_boxes);
     if (h->ev_marked) (void)hipEventDestroy(h->ev_marked);
     if (h->beam_angle) (void)hipFree(h->beam_angle);
@@ -1301,7 +1325,8 @@ static int score_chunks(const pfslam_handle *h)
 }
 
 // ---- persistent lattice-cell rows: host side ---------------------------------------------------------------------------------
-#define PF_CELLS_GRID 2048 /* workgroups (one wave each) of k_cells_update: grid-stride over the records */
+#define PF_CELLS_GRID 512 /* workgroups (one wave each) of k_cells_update, grid-stride over the records: two fit a CU (78 KB of LDS each), so 512
+                             are resident together -- 2048 of them queued through the few free places while the first 476 worked (56 us) */
 struct CellArgs { unsigned *tab; int *list, *cs; uint4 *pool; int *rec; };
 __global__ void k_cells_reset(int *cs)
 {
@@ -1317,6 +1342,8 @@ static int cells_wipe(pfslam_handle *h)
     h->cells_wipe_pending = false;
     h->cells_wipe_seq = h->seq;
     h->cells_wipes++;
+    h->cells_gen++;
+    h->cells_passes = 0;
     return 0;
 }
 // behind every insert into the tree (k_test_new), on the stream that ran it: the records' links are looked at, the cells that gained
@@ -1326,8 +1353,9 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
     if (!h->cell_tab || h->cells_wipe_pending) return 0; // (a pending wipe: the records belong to a map that is gone)
     const CellGeom geo{h->cfg.map_res_x, h->cfg.map_res_y, 1.0f / h->cfg.map_res_x, 1.0f / h->cfg.map_res_y};
     hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,
-                       h->cell_pool, h->cell_rec);
+                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15));
     HIPCHK(hipGetLastError());
+    h->cells_passes++;
     return 0;
 }
 
@@ -1374,12 +1402,17 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     if (use_cells && !h->cell_tab) {
         CHK(dalloc(&h->cell_tab, (size_t)PF_CELL_WIN * PF_CELL_WIN));
         CHK(dalloc(&h->cell_list, (size_t)PF_CELL_LIST_CAP));
-        CHK(dalloc(&h->cell_state, PF_CS_WORDS));
+        CHK(dalloc(&h->cell_state, PF_CS_ALLOC)); // ([64, 128): PF_CELLS_PROFILE builds)
+        HIPCHK(hipMemsetAsync(h->cell_state, 0, PF_CS_ALLOC * 4, h->stream));
         CHK(dalloc(&h->cell_rec, (size_t)PF_CELL_LIST_CAP * PF_REC_WORDS));
+        HIPCHK(hipMemsetAsync(h->cell_rec, 0, (size_t)PF_CELL_LIST_CAP * PF_REC_WORDS * 4, h->stream)); // generation 0: no record is written
         CHK(dalloc(&h->cell_pool, (size_t)PF_CELL_POOL_CAP + PF_ROW_SLACK));
+        CHK(dalloc(&h->cell_touched, (size_t)h->max_wall + 1));
+        HIPCHK(hipMemsetAsync(h->cell_touched, 0, 4, h->stream));
         CHK(dalloc(&h->fit_acc, (size_t)h->n));
         HIPCHK(hipEventCreateWithFlags(&h->ev_boxes, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_marked, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_walked, hipEventDisableTiming));
         HIPCHK(hipMemsetAsync(h->fit_acc, 0, (size_t)h->n * 4, h->stream));
         h->cells_wipe_pending = true;
     }
@@ -1387,7 +1420,8 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // kernel, on this stream (stage-level calls, the first pass after a wipe, per-phase timing).  Asynchronous pass (frame loops):
     // marking and the walk of the new cells run on the aux stream UNDER the scan-match kernel, whose lanes take the generic traversal
     // in a cell that has no rows yet; k_cells_update publishes them behind the frame's insert (launch_map_update_device).
-    const bool cells_sync = use_cells && (!h->cells_async || h->cells_wipe_pending || census != nullptr || h->census_log != nullptr);
+    static const int cells_mode = getenv("PFSLAM_CELLS_MODE") ? atoi(getenv("PFSLAM_CELLS_MODE")) : 0; // 1: always synchronous (A/B)
+    const bool cells_sync = use_cells && (!h->cells_async || h->cells_wipe_pending || census != nullptr || cells_mode == 1);
     if (use_cells && h->cells_wipe_pending) {
         CHK(join_map(h)); // the previous frame's k_cells_update is the table's last writer
         CHK(cells_wipe(h));
@@ -1439,10 +1473,14 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     const CellArgs ca{h->cell_tab, h->cell_list, h->cell_state, h->cell_pool, h->cell_rec};
     if (use_cells) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
         hipStream_t st = h->stream;
-        if (!cells_sync) { // behind whatever the aux stream still has to do for the previous frame (its map update, this frame's ICP)
+        if (!cells_sync) {
+            // On a stream of their own.  The marking pass needs the pose boxes and the scan only, and claims nothing but table words that
+            // are still zero, so it starts NOW -- beside the previous frame's map update on the aux stream, while this stream waits for
+            // that anyway -- and is over when the scan-match kernel starts: running beside THAT, its 1081 four-wave workgroups cost the
+            // scan-match kernel 27 us (0.373 -> 0.400 ms).  The walks wait for the previous frame's k_cells_update (below).
             HIPCHK(hipEventRecord(h->ev_boxes, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->aux, h->ev_boxes, 0));
-            st = h->aux;
+            HIPCHK(hipStreamWaitEvent(h->cstream, h->ev_boxes, 0));
+            st = h->cstream;
         }
         const int groups = (h->n + 63) / 64, per_block = PF_MARK_THREADS * PF_MARK_GROUPS;
         hipLaunchKernelGGL(k_cells_mark, dim3(h->nb, (groups + per_block - 1) / per_block), dim3(PF_MARK_THREADS), 0, st,
@@ -1451,7 +1489,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (!cells_sync) { // the new cells' walks from the root: records only, published behind this frame's insert
             HIPCHK(hipEventRecord(h->ev_marked, st));
             h->mark_on_aux = true;
-            hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec);
+            if (h->map_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_map, 0)); // the tree as the previous frame's insert left it, and behind that frame's k_cells_update
+            hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
+            HIPCHK(hipEventRecord(h->ev_walked, st));
+            h->walk_pending = true;
         }
         HIPCHK(hipGetLastError());
     }
@@ -1491,8 +1532,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     if (use_plan || use_cells) {
         const int groups = (h->n + 63) / 64;
         if (use_cells) { // rows of the new cells (and a look at every record's links)
+            if (cells_sync) h->cells_passes++;
             if (cells_sync)
-                hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, h->stream, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec);
+                hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, h->stream, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
         } else
             hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                                (const float *)h->scan, h->nb, kd_view(h), h->plan);
@@ -1687,9 +1729,10 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
 // the persistent lattice-cell rows: out[0] cells claimed since the last wipe (one record each), [1] live rows (one per sub-cell: up to four
 // per cell), [2] mean first-descent candidates per row, [3] mean re-descent candidates per row, [4] sub-cells without a row (too many
 // candidates / pool exhausted: generic lanes), [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell,
-// [8 .. 11] the last finished update: cells walked from the root / extended because a link gained a node / looked at and reused
-// as they were / newly claimed by the marking pass, [12] device flags (PF_CF_*: 1 list full, 2 pool full, 8 cloud far from the window
-// centre), [13] records walked, [14] wipes so far (host), [15] 0.  All zero when the last scoring pass did not use cell rows.
+// [8 .. 11] since the last wipe: cells walked from the root / extensions (a link of the cell had gained a node) / looks that found a
+// cell unchanged (reused as it was) / cells claimed by the marking passes, [12] device flags (PF_CF_*: 1 list full, 2 pool full,
+// 8 cloud far from the window centre), [13] publishing updates since the last wipe (the divisor of [9] [10]), [14] wipes so far,
+// [15] 0.  All zero when the last scoring pass did not use cell rows.
 extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
 {
     if (!h || !out) return fail("pfslam_cell_stats: bad argument");
@@ -1697,7 +1740,7 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
     if (!h->cell_state || !h->cells_valid) return 0;
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(settle(h));
-    int cs[PF_CS_WORDS];
+    int cs[PF_CS_ALLOC];
     HIPCHK(hipMemcpyAsync(cs, h->cell_state, sizeof(cs), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int rows = cs[PF_CS_ROWS];
@@ -1709,10 +1752,25 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
     out[5] = cs[PF_CS_POOL];
     out[6] = cs[PF_CS_OX];
     out[7] = cs[PF_CS_OY];
-    for (int k = 0; k < 4; k++) out[8 + k] = cs[PF_CS_LAST_FRESH + k];
+    for (int k = 0; k < 4; k++) out[8 + k] = cs[PF_CS_CUR_FRESH + k];
     out[12] = cs[PF_CS_FLAGS];
-    out[13] = cs[PF_CS_DONE];
+    out[13] = (double)h->cells_passes;
     out[14] = (double)h->cells_wipes;
+#ifdef PF_CELLS_PROFILE
+    {
+        int prof[64];
+        HIPCHK(hipMemcpy(prof, h->cell_state + 64, sizeof(prof), hipMemcpyDeviceToHost));
+        int waves = 0;
+        HIPCHK(hipMemcpy(&waves, h->cell_state + 63, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "k_cells_update<true> phases over %d wave-passes (mean / max us):", waves);
+        for (int p = 0; p < 9; p++) fprintf(stderr, "  [%d] %.2f / %.2f", p, waves ? prof[2 * p] * 0.01 / waves : 0.0, prof[2 * p + 1] * 0.01);
+        fprintf(stderr, "\n  slowest wave of the last 16 passes (us) / waves above 20 us:");
+        int wmax[32];
+        HIPCHK(hipMemcpy(wmax, h->cell_state + 96, sizeof(wmax), hipMemcpyDeviceToHost));
+        for (int p = 0; p < 16; p++) fprintf(stderr, " %.1f/%d", wmax[p] * 0.01, wmax[16 + p]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return 0;
 }
 

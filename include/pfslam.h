@@ -273,10 +273,11 @@ int pfslam_ubench_gather(pfslam_handle *h, double out[4]);
 int pfslam_plan_stats(pfslam_handle *h, double out[10]);
 /* the persistent lattice-cell rows (csrc/kd_cells.hip.inc): out[0] lattice cells claimed since the last wipe, [1] live rows (one per
  * sub-cell: up to four per cell), [2] mean first-descent candidates per row, [3] mean re-descent candidates per row, [4] sub-cells
- * without a row, [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell, [8 .. 11] the last finished update:
- * cells walked from the root / extended because one of their links gained a node / looked at and reused as they were / newly
- * claimed, [12] device flags (1 list full, 2 pool full, 8 cloud far from the window centre), [13] records walked, [14] wipes so
- * far, [15] 0.  All zero when the last scoring pass did not use cell rows. */
+ * without a row, [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell, [8 .. 11] since the last wipe:
+ * cells walked from the root / extensions (one of the cell's links had gained a node) / looks that found a cell unchanged / cells
+ * claimed, [12] device flags (1 list full, 2 pool full, 8 cloud far from the window centre), [13] publishing updates since the
+ * last wipe (divide [9] and [10] by it for per-frame figures), [14] wipes so far, [15] 0.  All zero when the last scoring pass did
+ * not use cell rows. */
 int pfslam_cell_stats(pfslam_handle *h, double out[16]);
 int pfslam_set_variant(pfslam_handle *h, int variant);
 

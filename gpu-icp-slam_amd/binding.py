@@ -25,6 +25,7 @@ SYMBOLS = [
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
     "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads",
+    "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
 ]
 
 
@@ -95,6 +96,10 @@ def load():
     L.pfslam_shard_score.argtypes = [vp]
     L.pfslam_shard_weights.argtypes = [vp]
     L.pfslam_shard_finish.argtypes = [vp]
+    L.pfslam_set_shard_balance.argtypes = [vp, i32]
+    L.pfslam_shard_balance_due.argtypes = [vp, i32, vp, vp]
+    L.pfslam_shard_balance_build.argtypes = [vp, i32]
+    L.pfslam_shard_balance_adopt.argtypes = [vp]
     L.pfslam_get_pose.argtypes = [vp, vp]
     L.pfslam_get_particles.argtypes = [vp, vp, vp]
     L.pfslam_get_map.argtypes = [vp, vp, vp]
@@ -433,6 +438,22 @@ class PfSlam:
 
     def shard_finish(self):
         _chk(self.L.pfslam_shard_finish(self._h), "pfslam_shard_finish")
+
+    # -- multi-GPU re-balance: one host build per node (include/pfslam.h)
+    def set_shard_balance(self, external):
+        _chk(self.L.pfslam_set_shard_balance(self._h, 1 if external else 0), "pfslam_set_shard_balance")
+
+    def shard_balance_due(self, frame):
+        """(due, n_nodes); books the frames in flight when the re-balance period hits."""
+        due, n = C.c_int(0), C.c_int(0)
+        _chk(self.L.pfslam_shard_balance_due(self._h, frame, C.byref(due), C.byref(n)), "pfslam_shard_balance_due")
+        return bool(due.value), n.value
+
+    def shard_balance_build(self, frame):
+        _chk(self.L.pfslam_shard_balance_build(self._h, frame), "pfslam_shard_balance_build")
+
+    def shard_balance_adopt(self):
+        _chk(self.L.pfslam_shard_balance_adopt(self._h), "pfslam_shard_balance_adopt")
 
     def step_grid(self, frame, scan):
         """One frame of the 2-D occupancy-grid variant (motion, grid score + weights, grid update, resample)."""

@@ -203,6 +203,7 @@ struct pfslam_handle {
     // the rows persist across frames (kd_cells.hip.inc): wiped when the map is replaced (set_map, re-balance) or the device asks for
     // it in a frame's header (list / pool exhausted, cloud far from the window centre)
     bool cells_wipe_pending = false;
+    bool balance_external = false; // multi-GPU: ONE rank of the node re-balances, the others adopt its arrays (pfslam_set_shard_balance)
     int cells_wipe_seq = 0;       // header flags of frames with an older ticket predate the last wipe
     bool score_on_aux = false;    // pfslam_step asks for it; launch_score grants it (scored_on_aux) in a frame whose cell passes are asynchronous
     bool scored_on_aux = false;
@@ -1069,6 +1070,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     // cell_to_point (ROUND_FRAC, kernel.cu:52) makes map points
     std::atomic<int> bad{-1}, nonplanar{0}, nonintegral{0}, offlattice{0};
     const float rx = h->cfg.map_res_x, ry = h->cfg.map_res_y, ix = 1.0f / rx, iy = 1.0f / ry;
+    const float xmax = rx * (float)PF_LATTICE_KMAX, ymax = ry * (float)PF_LATTICE_KMAX;
     parallel_chunks(n, [&](int lo, int hi, int) {
         bool np = false, ni = false, ol = false;
         for (int i = lo; i < hi; i++) {
@@ -1085,7 +1087,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
             // |w| <= 2^13 keeps every partial sum of 1081 weights below 2^24, i.e. exact in any order
             ni |= !(nd.w == (float)(int)nd.w && fabsf(nd.w) <= 8192.0f);
             if (!ol) {
-                if (!(fabsf(nd.x) < 2e4f && fabsf(nd.y) < 2e4f)) ol = true; // |k| < 2^20 at 2.5 cm; NaN fails
+                if (!(fabsf(nd.x) < xmax && fabsf(nd.y) < ymax)) ol = true; // |k| < 2^20 cells per axis (PF_LATTICE_KMAX); NaN fails
                 else {
                     const float kx = roundf(nd.x * ix), ky = roundf(nd.y * iy);
                     ol = !((kx * rx == nd.x || (kx + 1.0f) * rx == nd.x || (kx - 1.0f) * rx == nd.x) &&
@@ -1111,7 +1113,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kw, w.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    const int state[4] = {n, 0, 0, 0};
+    const int state[4] = {n, planar, integral ? 1 : 0, lattice ? 1 : 0}; // [1 .. 3]: for the ranks that adopt this tree (pfslam_shard_balance_adopt)
     HIPCHK(hipMemcpyAsync(h->kd_state, state, 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->h_nodes.assign(nodes, nodes + n);
@@ -1935,6 +1937,12 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
     case 15: *ptr = h->packs; *bytes = (size_t)32 * h->world; break;
     case 16: *ptr = h->pblk; *bytes = (size_t)3 * h->stride * 4; break;
     case 17: *ptr = h->gpose; *bytes = (size_t)h->world * 3 * h->stride * 4; break;
+    // the map as the device holds it (pfslam_shard_balance_*: broadcast from the rank that re-balanced): kd_capacity entries each
+    case 20: *ptr = h->hot; *bytes = (size_t)h->kd_cap * 16; break;
+    case 21: *ptr = h->parent; *bytes = (size_t)h->kd_cap * 4; break;
+    case 22: *ptr = h->kz; *bytes = (size_t)h->kd_cap * 4; break;
+    case 23: *ptr = h->kw; *bytes = (size_t)h->kd_cap * 4; break;
+    case 24: *ptr = h->kd_state; *bytes = 16; break;
     default: return fail("pfslam_device_ptr: unknown buffer");
     }
     return 0;

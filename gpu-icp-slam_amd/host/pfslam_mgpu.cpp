@@ -124,6 +124,7 @@ static int launch(int argc, char **argv, const Args &a)
             setenv("PFSLAM_WORLD", std::to_string(a.gpus).c_str(), 1);
             setenv("PFSLAM_LOCAL_RANK", std::to_string(r).c_str(), 1);
             setenv("PFSLAM_ID_FILE", id_file.c_str(), 1);
+            setenv("LOCAL_WORLD_SIZE", std::to_string(a.gpus).c_str(), 0); // the host kd build shares the node's cores with the other ranks (csrc/kd_host.cpp)
             execv("/proc/self/exe", argv);
             perror("execv");
             _exit(127);
@@ -198,13 +199,34 @@ struct Rank {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_p = nullptr, ev_pg = nullptr, ev_w = nullptr, ev_wg = nullptr;
-    int stride = 0, world = 1, collectives = 0;
+    int stride = 0, world = 1, collectives = 0, balance_builds = 0, balance_broadcasts = 0;
 };
 
 // the sharded frame of include/pfslam.h: three all-gathers on a fixed schedule, NO host wait (the frame is booked one step
 // later from its pinned header, like pfslam_step's)
 static int step(Rank &R, int frame, const float *scan)
 {
+    if (R.world > 1) { // KDTree::Balance (frame % 100 == 5) ONCE per node: rank 0 builds, the others take its device arrays (28 B per node)
+        int due = 0, n_nodes = 0;
+        PF(pfslam_shard_balance_due(R.h, frame, &due, &n_nodes));
+        if (due) {
+            if (g_rank == 0) {
+                PF(pfslam_shard_balance_build(R.h, frame));
+                R.balance_builds++;
+            }
+            static const int ids[5] = {20, 21, 22, 23, 24};
+            const size_t per_node[5] = {16, 4, 4, 4, 0};
+            for (int k = 0; k < 5; k++) {
+                void *p = nullptr;
+                size_t bytes = 0;
+                PF(pfslam_device_ptr(R.h, ids[k], &p, &bytes));
+                const size_t count = k < 4 ? per_node[k] * (size_t)n_nodes : 16;
+                NCCL(ncclBroadcast(p, p, count, ncclChar, 0, R.comm, R.stream));
+            }
+            if (g_rank != 0) PF(pfslam_shard_balance_adopt(R.h));
+            R.balance_broadcasts++;
+        }
+    }
     int seeded = 0;
     PF(pfslam_shard_disperse(R.h, frame, scan, &seeded));
     if (seeded) return 0; // the first scan only seeds the (replicated) map
@@ -295,6 +317,7 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
     cfg.shard_stride = stride;
     PF(pfslam_create(&cfg, &R.h));
     PF(pfslam_set_stream(R.h, R.stream));
+    if (world > 1) PF(pfslam_set_shard_balance(R.h, 1));
     PF(pfslam_set_map(R.h, reinterpret_cast<const pfslam_node *>(map.data()), n_nodes));
     double *scratch = nullptr;
     HIP(hipMalloc((void **)&scratch, 8));

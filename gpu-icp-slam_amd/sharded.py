@@ -70,6 +70,14 @@ class GpuBuffers:
         t = self.torch
         return self._view(16, "<f4", 4, t.float32), self._view(17, "<f4", 4, t.float32)
 
+    def tree_buffers(self, n_nodes):
+        """The device's map arrays, first n_nodes entries (hot records 16 B, parents, z / z-level links, weights: 4 B each) + the
+        16-byte state: what the rank that re-balanced broadcasts to the others."""
+        t = self.torch
+        return [self._view(20, "<i4", 4, t.int32)[:4 * n_nodes], self._view(21, "<i4", 4, t.int32)[:n_nodes],
+                self._view(22, "<i4", 4, t.int32)[:n_nodes], self._view(23, "<i4", 4, t.int32)[:n_nodes],
+                self._view(24, "<i4", 4, t.int32)]
+
 
 class ShardedSlam:
     def __init__(self, pkg, n_global, rank, world, device=0, dist=None, torch=None, engine=None, buffers=None, **kw):
@@ -89,6 +97,11 @@ class ShardedSlam:
             buffers = GpuBuffers(engine, torch, device)
         self.eng, self.buf = engine, buffers
         self.collectives = 0   # all-gathers issued: 3 in every frame (fixed schedule)
+        # KDTree::Balance (frame % 100 == 5) ONCE per node: rank 0 builds, the others receive the device arrays (28 B per node)
+        self.balance_builds = 0      # host builds this rank ran
+        self.balance_broadcasts = 0  # re-balances this rank took part in
+        if world > 1:
+            engine.set_shard_balance(True)
 
     # -- pass-throughs
     def set_map(self, tree): self.eng.set_map(tree)
@@ -114,6 +127,17 @@ class ShardedSlam:
     def step(self, frame, scan):
         """One frame, enqueued: nothing here waits for the device (see include/pfslam.h, pfslam_shard_*)."""
         e, b = self.eng, self.buf
+        if self.world > 1:
+            due, n_nodes = e.shard_balance_due(frame)   # the same answer on every rank: frame number and (replicated) map size
+            if due:
+                if self.rank == 0:
+                    e.shard_balance_build(frame)
+                    self.balance_builds += 1
+                for t in b.tree_buffers(n_nodes):       # rank 0's re-built map, straight from / into the device arrays
+                    self.dist.broadcast(t, src=0)
+                if self.rank != 0:
+                    e.shard_balance_adopt()
+                self.balance_broadcasts += 1
         if e.shard_disperse(frame, scan):       # first scan seeds the map (kernel.cu:1714-1717); replicated
             return
         if self.world == 1:                     # buffers 10 / 17 alias 5 / 16: only the record moves (to its gathered slot)

@@ -219,6 +219,16 @@ int pfslam_shard_disperse(pfslam_handle *h, int frame, const float *scan_host, i
 int pfslam_shard_score(pfslam_handle *h);
 int pfslam_shard_weights(pfslam_handle *h);
 int pfslam_shard_finish(pfslam_handle *h);
+/* Multi-GPU re-balance, ONE host build per node (the ranks hold identical maps): after pfslam_set_shard_balance(h, 1) the sharded
+ * frame does not re-balance by itself.  In front of pfslam_shard_disperse every rank calls pfslam_shard_balance_due (books the frames
+ * in flight when the period hits; *n_nodes = map size).  If due: the root rank calls pfslam_shard_balance_build (KDTree::Balance,
+ * kdtree.cpp:31-40, on the host with all usable cores), every rank broadcasts pfslam_device_ptr buffers 20 (hot records, 16 B per
+ * node), 21 (parents), 22 (z / z-level links), 23 (weights; 4 B per node each: the first n_nodes entries) and 24 (16 bytes of
+ * state) from the root on the handle's stream, and the other ranks call pfslam_shard_balance_adopt. */
+int pfslam_set_shard_balance(pfslam_handle *h, int external);
+int pfslam_shard_balance_due(pfslam_handle *h, int frame, int *due, int *n_nodes);
+int pfslam_shard_balance_build(pfslam_handle *h, int frame);
+int pfslam_shard_balance_adopt(pfslam_handle *h);
 /* stage-level merge hooks (the sharded frame above does not need them): local packed keys into the stats buffer 0
  * ([0] max key, [1] negated-min key: MAX-reduce across ranks), then weights + this rank's share of the best pose in buffer 8
  * (zero on non-owners: SUM-reduce across ranks) */

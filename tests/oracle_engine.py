@@ -63,6 +63,10 @@ class OracleBuffers:
     def pose_blocks(self):
         return torch.from_numpy(self.eng.pblk), torch.from_numpy(self.eng.gpose)
 
+    def tree_buffers(self, n_nodes):
+        # the oracle keeps the reference's 32-byte nodes: one buffer of bytes does for the five device arrays of the GPU handle
+        return [torch.from_numpy(self.eng.tree[:n_nodes].view(np.uint8).reshape(-1))]
+
 
 class OracleShardEngine:
     """Rank `goff // stride` of a job of `gn` particles: the same buffers as the GPU handle (include/pfslam.h, buffers 5, 10,
@@ -92,6 +96,7 @@ class OracleShardEngine:
         self.scan = None
         self.src = None
         self.icp_delta = None
+        self.external, self.builds, self.adopted = False, 0, 0
 
     # ---- helpers
     def _aos(self):
@@ -116,6 +121,19 @@ class OracleShardEngine:
     def maybe_balance(self, frame):
         if self.period > 0 and frame % self.period == 5 and self.size > 0:
             O.lib().orc_kd_balance(O.P(self.tree), self.size)
+            self.builds += 1
+
+    # one re-balance per node (include/pfslam.h, pfslam_shard_balance_*)
+    def set_shard_balance(self, external): self.external = bool(external)
+
+    def shard_balance_due(self, frame):
+        return (self.period > 0 and frame % self.period == 5 and self.size > 0), self.size
+
+    def shard_balance_build(self, frame):
+        self.maybe_balance(frame)
+
+    def shard_balance_adopt(self):
+        self.adopted += 1
 
     def update_map_kd(self):
         self.size = oracle_map_update(self.tree, self.size, self.robot, self.scan, self.cap)
@@ -153,7 +171,8 @@ class OracleShardEngine:
     def shard_disperse(self, frame, scan):
         """pfslam_shard_disperse: scan, re-balance if due, (first scan: seed the map), ICP solve, dispersion."""
         self.set_scan(scan)
-        self.maybe_balance(frame)
+        if not self.external:
+            self.maybe_balance(frame)
         self.frame = frame
         self._trace = {"best": -1, "resampled": 0, "kd_size": self.size}
         if self.size == 0:

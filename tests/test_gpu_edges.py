@@ -220,6 +220,41 @@ def test_non_default_map_and_beam_count(pkg):
         pkg.PfSlam(8, map_scale=(40.0, 30.0))
 
 
+@pytest.mark.parametrize("res,scale", [(0.03, 36.0), (0.1, 40.0)])
+def test_cell_rows_at_other_resolutions(pkg, res, scale):
+    """The lattice-cell rows (csrc/kd_cells.hip.inc) are exact for |k| < 2^20 cells per axis at ANY resolution (PF_LATTICE_KMAX): a
+    3 cm and a 10 cm map, rows forced on at 300 particles, replay bit-identically; a map with one point beyond the range is scored
+    without rows (the round-2 plan), bit-identically too."""
+    segs, frames = pkg.synth.corridor_sequence(10, seed=9)
+    patch = O.Patch(scale, scale, res, res)
+    kw = dict(kd_capacity=1 << 16)
+    o = O.Slam(300, patch=patch, **kw)
+    h = pkg.PfSlam(300, map_scale=(scale, scale), map_res=(res, res), **kw)
+    h.set_variant(3)
+    for f, (_, scan) in enumerate(frames, start=1):
+        o.step(f, scan); h.step(f, scan)
+        assert h.trace() == o.trace(), f
+        assert (h.pose.view(np.int32) == o.pose.view(np.int32)).all()
+    assert h.map().tobytes() == o.tree().tobytes() and o.kd_size > 100
+    st = h.cell_stats()
+    assert st["rows"] > 100 and st["flags"] == 0
+    # the same map with one point pushed beyond 2^20 cells: off the range -> no rows, same scores
+    tree = o.tree().copy()
+    leaf = int(np.where((tree["left"] < 0) & (tree["right"] < 0))[0][0])
+    p = o.particles().copy()
+    scan = frames[-1][1]
+    far = tree.copy()
+    far["x"][leaf] = np.float32(res) * np.float32(2 ** 20 + 5)
+    h2 = pkg.PfSlam(300, map_scale=(scale, scale), map_res=(res, res), **kw)
+    h2.set_variant(3)
+    h2.set_map(far); h2.set_particles(p); h2.set_scan(scan)
+    got = h2.score_kd()
+    assert h2.cell_stats()["rows"] == 0 and h2.plan_stats()["rows"] > 0
+    o2 = O.Slam(300, patch=patch, **kw)
+    assert (bits(got) == bits(O.score_kd(far, p, scan))).all()
+    h.close(); h2.close(); o.close(); o2.close()
+
+
 def test_differential_fuzz_of_the_frame_loop():
     """20 s of tests/fuzz_step.py: random particle counts / beam counts / map geometry / parity flags / balance periods,
     adversarial scans (NaN, Inf, zero, negative, out of range), clouds at the map edge, tiny capacity headroom -- KD and

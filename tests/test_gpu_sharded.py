@@ -36,8 +36,24 @@ def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
             e.synchronize()
         torch.cuda.synchronize()
 
+    for e in engs:
+        e.set_shard_balance(True)   # ONE KDTree::Balance per job (include/pfslam.h, pfslam_shard_balance_*): rank 0 builds ...
+    n_adopted = 0
     for f, (pose, scan) in enumerate(frames, start=1):
         o.step(f, scan)
+        due = [e.shard_balance_due(f) for e in engs]
+        assert len(set(due)) == 1
+        if due[0][0]:
+            engs[0].shard_balance_build(f)
+            sync()
+            src = bufs[0].tree_buffers(due[0][1])
+            for b in bufs[1:]:                                                  # ... the others get its device arrays ("broadcast")
+                for dst, s_ in zip(b.tree_buffers(due[0][1]), src):
+                    dst.copy_(s_)
+            sync()
+            for e in engs[1:]:
+                e.shard_balance_adopt()
+                n_adopted += 1
         seeded = [e.shard_disperse(f, scan) for e in engs]
         assert len(set(seeded)) == 1
         if seeded[0]:
@@ -71,7 +87,7 @@ def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
             assert te["best"] == t["best"] and te["resampled"] == t["resampled"]
             assert (bits(e.pose) == bits(o.pose)).all()
             assert e.kd_size == o.kd_size
-    assert n_resampled > 0
+    assert n_resampled > 0 and n_adopted == world - 1      # frame 5 re-balances (12 frames)
     want = o.particles()
     got = [e.particles() for e in engs]
     for fld in ("x", "y", "theta", "w"):

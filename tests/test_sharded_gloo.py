@@ -43,6 +43,11 @@ def _worker(rank, world, port, n_global, n_frames, strict, out_dir):
     # the fixed schedule: three all-gathers in every frame (pose blocks, records, weights), whether it resamples or not
     n_stepped = sum(1 for row in log if row[0] >= 0)
     assert s.collectives == 3 * n_stepped, (s.collectives, n_stepped)
+    # KDTree::Balance at frame 5: ONE host build in the whole job (rank 0), everybody else adopts the broadcast map
+    builds = torch.tensor([eng.builds], dtype=torch.int64)
+    dist.all_reduce(builds)
+    assert int(builds.item()) == 1 and s.balance_broadcasts == 1, (int(builds.item()), s.balance_broadcasts)
+    assert eng.builds == (1 if rank == 0 else 0) and eng.adopted == (0 if rank == 0 else 1) and s.balance_builds == eng.builds
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=eng.x, y=eng.y, th=eng.th, w=eng.w, log=np.array(log, np.int64),
              tree=eng.tree[:eng.size])
     dist.barrier()

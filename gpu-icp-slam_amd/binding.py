@@ -395,7 +395,7 @@ class PfSlam:
         out = (C.c_double * 16)()
         _chk(self.L.pfslam_cell_stats(self._h, out), "pfslam_cell_stats")
         keys = ("cells", "rows", "candidates", "redescent_candidates", "cells_without_row", "pool_slots", "window_kx", "window_ky",
-                "walked_from_root", "extended", "reused", "claimed", "flags", "updates", "wipes")
+                "walked_from_root", "extended", "reused", "claimed", "flags", "updates", "wipes", "suspended")
         return dict(zip(keys, [float(v) for v in out]))
 
     def ubench_gather(self):

@@ -69,7 +69,8 @@ struct HostHeader {
     float pose[4];
     int64_t stats[2];
     int32_t seq; // ticket of the frame that wrote this slot
-    int32_t pad[15];
+    float cloud_sigma; // spread of the particle cloud as the frame's lane order saw it (m; max of x, y, reach x heading)
+    int32_t pad[14];
 };
 static_assert(sizeof(HostHeader) == 128, "HostHeader is two 64-byte lines");
 #define PF_HDR_SLOTS 4 /* header / scan staging slots: frames in flight + 1 (PF_MAX_LAG + 2) */
@@ -203,6 +204,12 @@ struct pfslam_handle {
     // the rows persist across frames (kd_cells.hip.inc): wiped when the map is replaced (set_map, re-balance) or the device asks for
     // it in a frame's header (list / pool exhausted, cloud far from the window centre)
     bool cells_wipe_pending = false;
+    // spread of the cloud (k_cell_count -> frame header -> here, one frame late; set_particles estimates it on the host): the cell rows'
+    // marking pass costs the AREA of the waves' beam-end boxes in lattice cells, so a wide cloud is scored with the round-2 plan
+    float cloud_sigma = 0.0f;
+    float *d_sigma = nullptr;
+    bool cells_suspended = false;  // the list / pool overflowed twice in a row: round-2 plan until the next upload_tree
+    int cells_full_frame = -1;
     bool balance_external = false; // multi-GPU: ONE rank of the node re-balances, the others adopt its arrays (pfslam_set_shard_balance)
     int cells_wipe_seq = 0;       // header flags of frames with an older ticket predate the last wipe
     bool score_on_aux = false;    // pfslam_step asks for it; launch_score grants it (scored_on_aux) in a frame whose cell passes are asynchronous
@@ -539,7 +546,7 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
 // table has just been wiped, and reports a cloud that has drifted away from the window's middle
 __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x, const float *__restrict__ y,
                                                     const float *__restrict__ th, int n, float reach, int bits,
-                                                    unsigned *__restrict__ cell, int *__restrict__ hist, int *__restrict__ cs, CellGeom geo)
+                                                    unsigned *__restrict__ cell, int *__restrict__ hist, int *__restrict__ cs, CellGeom geo, float *__restrict__ sigma_out)
 {
     __shared__ float red[4];
     const int ns = min(n, 1024); // cloud statistics, identical in every block
@@ -569,6 +576,7 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     const float dev_x = sqrtf(block_sum_256(vx, red) * inv), dev_y = sqrtf(block_sum_256(vy, red) * inv);
     const float dev_t = sqrtf(block_sum_256(vt, red) * inv) * reach;
     const float D = (float)(1 << bits), half = 0.5f * D, top = D - 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sigma_out[0] = fmaxf(fmaxf(dev_x, dev_y), dev_t); // -> frame header -> host (organisation of the next pass)
     const float e = fmaxf(6.4f / D * fmaxf(fmaxf(dev_x, dev_y), dev_t), 2.5e-4f);
     const float cx = 1.0f / e, cy = 1.0f / e, ct = reach / e;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -814,6 +822,8 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->d_count, 4));
     CHK(dalloc(&h->wall_leaf, (size_t)h->max_wall));
     CHK(dalloc(&h->kd_state, 4));
+    CHK(dalloc(&h->d_sigma, 4));
+    HIPCHK(hipMemsetAsync(h->d_sigma, 0, 16, h->stream));
     HIPCHK(hipMemsetAsync(h->kd_state, 0, 16, h->stream));
     // headers and scan staging: pinned, coherent (the device writes a header while the stream keeps running, the host may poll it)
     HIPCHK(hipHostMalloc((void **)&h->h_hdr, PF_HDR_SLOTS * sizeof(HostHeader), hipHostMallocCoherent | hipHostMallocMapped));
@@ -891,7 +901,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
                     h->fit, h->fit_i, h->partial, h->mkey, h->order2, h->cells, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
-                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->wall_leaf, h->kd_state};
+                    h->chunk_max, h->tile_tot, h->tile_off, h->tile_pmax, h->src, h->grid, h->d_count, h->wall_leaf, h->kd_state, h->d_sigma};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_global) {
@@ -1124,6 +1134,8 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     h->integral_w = integral;
     h->lattice_ok = lattice;
     h->cells_wipe_pending = true; // rows of the previous map
+    h->cells_suspended = false;
+    h->cells_full_frame = -1;
     return 0;
 }
 
@@ -1143,6 +1155,18 @@ extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, 
     std::vector<float> tmp(4 * (size_t)n);
     for (int i = 0; i < n; i++) {
         tmp[i] = p[i].x; tmp[n + i] = p[i].y; tmp[2 * (size_t)n + i] = p[i].theta; tmp[3 * (size_t)n + i] = p[i].w;
+    }
+    { // spread of the new cloud, as k_cell_count will see it (first 1024 slots): decides how the next scoring pass is organised
+        const int ns = std::min(n, 1024);
+        double m[3] = {0, 0, 0}, v[3] = {0, 0, 0};
+        for (int i = 0; i < ns; i++) { m[0] += p[i].x; m[1] += p[i].y; m[2] += p[i].theta; }
+        for (int k = 0; k < 3; k++) m[k] /= ns;
+        for (int i = 0; i < ns; i++) {
+            const double d0 = p[i].x - m[0], d1 = p[i].y - m[1], d2 = p[i].theta - m[2];
+            v[0] += d0 * d0; v[1] += d1 * d1; v[2] += d2 * d2;
+        }
+        const double sg = std::max(std::max(std::sqrt(v[0] / ns), std::sqrt(v[1] / ns)), std::sqrt(v[2] / ns) * h->scan_reach);
+        h->cloud_sigma = std::isfinite(sg) ? (float)sg : 0.0f;
     }
     HIPCHK(hipMemcpyAsync(h->x, &tmp[0], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->y, &tmp[n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -1408,7 +1432,15 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // 0.351 / 1.307 ms (tools/experiments/r03/cells_threshold.py): organised from ~4.6 k particles on.
     static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 4608;
     const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
-    const bool use_cells = organised && h->lattice_ok && h->variant != 4; // lattice-cell rows (kd_cells.hip.inc)
+    // The marking pass of the cell rows costs the area of a wave's beam-end box in lattice cells: a wave's 64 Hilbert neighbours span
+    // ~(64 D^3 / N)^(1/3) of the D^3 cells laid over +-3.2 sigma, in position and (x reach) in heading.  Up to ~24 cells per side the
+    // rows win (0.5 m of spread at 100 k particles and 2.5 cm: cell rows 0.48 / 0.84 / 1.9 ms at sigma 0.05 / 0.2 / 0.5 m against 1.2 / 1.9 / 2.4 ms
+    // for the plan); at 1 m they took 60 ms against 2.7 (tools/sigma_sweep.py, profiles/r04_sigma_sweep.json).  variant 3 forces them.
+    const float Dside = h->n <= 400000 ? 64.0f : 128.0f;
+    const float box_cells = 2.0f * (6.4f * h->cloud_sigma / Dside) * cbrtf(64.0f * Dside * Dside * Dside / (float)h->n) / std::min(h->cfg.map_res_x, h->cfg.map_res_y);
+    static const float box_max = getenv("PFSLAM_CELLS_BOX_MAX") ? (float)atof(getenv("PFSLAM_CELLS_BOX_MAX")) : 24.0f;
+    const bool narrow = h->variant == 3 || !(box_cells > box_max);
+    const bool use_cells = organised && h->lattice_ok && h->variant != 4 && !h->cells_suspended && narrow; // lattice-cell rows (kd_cells.hip.inc)
     const bool use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);
     const CellGeom geo{h->cfg.map_res_x, h->cfg.map_res_y, 1.0f / h->cfg.map_res_x, 1.0f / h->cfg.map_res_y};
     if (use_cells && !h->cell_tab) {
@@ -1444,7 +1476,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         const int bits = h->n <= 400000 ? 6 : PF_CELL_BITS_MAX, ncell = 1 << (3 * bits);
         int *hist = h->cells, *cursor = h->cells + ncell, *tile_tot = h->cells + 2 * ncell;
         hipLaunchKernelGGL(k_cell_count, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan_reach * theta_weight, bits, h->mkey, hist,
-                           use_cells ? h->cell_state : (int *)nullptr, geo);
+                           use_cells ? h->cell_state : (int *)nullptr, geo, h->d_sigma);
         hipLaunchKernelGGL(k_cell_scan, dim3(ncell / 1024), dim3(256), 0, h->stream, hist, cursor, tile_tot);
         hipLaunchKernelGGL(k_cell_scatter, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->mkey, h->n, cursor, tile_tot, ncell / 1024, h->order2);
         HIPCHK(hipGetLastError());
@@ -1761,11 +1793,14 @@ extern "C" int pfslam_plan_stats(pfslam_handle *h, double out[10])
 // [8 .. 11] since the last wipe: cells walked from the root / extensions (a link of the cell had gained a node) / looks that found a
 // cell unchanged (reused as it was) / cells claimed by the marking passes, [12] device flags (PF_CF_*: 1 list full, 2 pool full,
 // 8 cloud far from the window centre), [13] publishing updates since the last wipe (the divisor of [9] [10]), [14] wipes so far,
-// [15] 0.  All zero when the last scoring pass did not use cell rows.
+// [15] 1 = suspended (list / pool overflowed twice in a row: the round-2 plan scores until the map is replaced or re-balanced).
+// [0 .. 13] are zero when the last scoring pass did not use cell rows.
 extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
 {
     if (!h || !out) return fail("pfslam_cell_stats: bad argument");
     for (int k = 0; k < 16; k++) out[k] = 0.0;
+    out[14] = (double)h->cells_wipes;
+    out[15] = h->cells_suspended ? 1.0 : 0.0;
     if (!h->cell_state || !h->cells_valid) return 0;
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(settle(h));
@@ -1785,6 +1820,7 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
     out[12] = cs[PF_CS_FLAGS];
     out[13] = (double)h->cells_passes;
     out[14] = (double)h->cells_wipes;
+    out[15] = h->cells_suspended ? 1.0 : 0.0;
 #ifdef PF_CELLS_PROFILE
     {
         int prof[64];

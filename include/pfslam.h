@@ -286,8 +286,9 @@ int pfslam_plan_stats(pfslam_handle *h, double out[10]);
  * without a row, [5] 16-byte pool slots used, [6] [7] lattice index of the window's corner cell, [8 .. 11] since the last wipe:
  * cells walked from the root / extensions (one of the cell's links had gained a node) / looks that found a cell unchanged / cells
  * claimed, [12] device flags (1 list full, 2 pool full, 8 cloud far from the window centre), [13] publishing updates since the
- * last wipe (divide [9] and [10] by it for per-frame figures), [14] wipes so far, [15] 0.  All zero when the last scoring pass did
- * not use cell rows. */
+ * last wipe (divide [9] and [10] by it for per-frame figures), [14] wipes so far, [15] 1 = suspended: the list / pool overflowed
+ * twice within 16 frames (a cloud too wide for the table), the round-2 plan scores until the map is replaced or re-balanced.
+ * [0 .. 13] are zero when the last scoring pass did not use cell rows. */
 int pfslam_cell_stats(pfslam_handle *h, double out[16]);
 int pfslam_set_variant(pfslam_handle *h, int variant);
 

@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--cloud-sigma", type=float, default=0.0, help="start from a Gaussian cloud of this spread (m; heading: sigma / 8 rad) instead of the dispersed start cloud")
+    ap.add_argument("--dry-collectives", action="store_true", help="also time the frame's collectives on their own (per-rank wall times in the line); with one rank: the fields, no traffic")
     return ap.parse_args()
 
 
@@ -128,6 +130,15 @@ def cpu_baseline(O, tree, particles, scan, sample, map_points):
                   "(gcc -O3 -mavx2 -mfma), %d pthreads = usable cores (sched affinity and cgroup quota; %d logical CPUs); "
                   "single thread: %.0f evals/s on %d particles" % (sample, map_points, cores, logical, rate1, one),
     }, visits / max(valid, 1), valid / one
+
+
+def pmc_busy(pmc, avgp, name, units, clock_ghz, quad):
+    """Busy fraction of `units` hardware units from a cycle counter summed over them: counter (x 4 if it counts quad-cycles) / units /
+    cycles, cycles = the kernel's mean duration inside the PMC pass that collected the counter x the measured clock."""
+    v, ms = avgp.get(name), (pmc.get("pass_kernel_ms") or {}).get(name)
+    if not v or not ms or not clock_ghz:
+        return None
+    return v * (4.0 if quad else 1.0) / units / (ms * 1e-3 * clock_ghz * 1e9)
 
 
 def find_pmc(explicit, n_local, map_points):
@@ -258,6 +269,10 @@ def self_launch(n):
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        if not a.same_device:
+            ndev = importlib.import_module("gpu-icp-slam_amd").device_count()
+            if a.gpus > ndev:
+                raise SystemExit("--gpus %d but only %d device(s) are visible: refusing to launch ranks" % (a.gpus, ndev))
         raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -268,6 +283,9 @@ def main():
     pkg = importlib.import_module("gpu-icp-slam_amd")
     if pkg.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: libpfslam_hip.so has no CPU fallback")
+    if not a.same_device and max(a.gpus, 1) > pkg.device_count():
+        raise SystemExit("--gpus %d but only %d device(s) are visible: refusing to start (a rank without a GPU of its own would hang "
+                         "the others in ncclCommInitRank)" % (a.gpus, pkg.device_count()))
 
     dist = None
     torch = None
@@ -313,6 +331,13 @@ def main():
         # first scoring launches behave like steady state instead of scoring 100 k coincident particles
         for f in range(1, 6):
             e.motion_update(f)
+        if a.cloud_sigma > 0 and not distributed:  # a wide start cloud (the organisation follows the cloud's spread)
+            p = e.particles().copy()
+            rs = np.random.RandomState(7)
+            p["x"] = rs.normal(0, a.cloud_sigma, len(p)).astype(np.float32)
+            p["y"] = rs.normal(0, a.cloud_sigma, len(p)).astype(np.float32)
+            p["theta"] = rs.normal(0, a.cloud_sigma / 8.0, len(p)).astype(np.float32)
+            e.set_particles(p)
         return e
 
     eng = make_engine()
@@ -333,9 +358,45 @@ def main():
         dt = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)                       # every rank's own wall time: a SCALE record explains itself
+            per_rank_s.append([float(v.item()) for v in every])
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    per_rank_s = []
+
+    def time_collectives(reps=20):
+        """The frame's collectives on their own, same buffers and sizes as the frame issues them, `reps` each, bracketed by events on
+        the stream the frame runs on (ms per call, this rank).  One rank: the sizes only -- nothing moves."""
+        sizes = {"pose_blocks_bytes_per_rank": 3 * eng.stride * 4 if hasattr(eng, "stride") else 3 * n_local * 4,
+                 "records_bytes_per_rank": 32, "weights_bytes_per_rank": (eng.stride if hasattr(eng, "stride") else n_local) * 4,
+                 "balance_broadcast_bytes": 28 * int(e0.kd_size) + 16}
+        res = {"sizes": sizes, "world": world, "ms": None,
+               "note": "pose blocks and weights are gathered on the collective's own stream under the scan-match kernel / the map update; "
+                       "the 32-byte records sit on the frame's critical chain; the broadcast happens once per KDTree::Balance (100 frames)"}
+        if dist is None or world == 1:
+            return res
+        b = eng.buf
+        local, glob = b.pose_blocks()
+        ops = {"pose_blocks": lambda: dist.all_gather_into_tensor(glob, local),
+               "records": lambda: dist.all_gather_into_tensor(b.packs, b.pack),
+               "weights": lambda: dist.all_gather_into_tensor(b.gw, b.w)}
+        ms = {}
+        for name, op in ops.items():
+            op(); torch.cuda.synchronize(); dist.barrier()
+            e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e_a.record()
+            for _ in range(reps):
+                op()
+            e_b.record(); torch.cuda.synchronize()
+            ms[name] = e_a.elapsed_time(e_b) / reps
+        t = torch.tensor([ms[k] for k in sorted(ms)], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        res["ms"] = {k: [float(v[i].item()) for v in every] for i, k in enumerate(sorted(ms))}
+        return res
 
     frame = FIRST_FRAME
     for k in range(a.warmup):
@@ -364,6 +425,7 @@ def main():
     r0.close()
     del rep, r0
 
+    coll = time_collectives() if (world > 1 or a.dry_collectives) else None   # every rank takes part
     out = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
@@ -379,12 +441,18 @@ def main():
                        "frames": "%d..%d (KDTree::Balance falls on frame %% 100 == 5: not inside this window, see long_run)" % (frame - a.steps, frame - 1),
                        "kd_size_end": trace.get("kd_size")},
         }
+        if per_rank_s:
+            out["per_rank_ms_per_step"] = [v / a.steps * 1e3 for v in per_rank_s[0]]   # each rank's own wall clock over the timed window
+        if coll is not None:
+            out["collectives"] = coll
+        if a.cloud_sigma > 0:
+            out["config"]["cloud_sigma_m"] = a.cloud_sigma
         import oracle_lib as O
         # ---- roofline of the dominant kernel (rank 0's launches) -------------------------------------
         tree_end = np.ascontiguousarray(e0.map(), dtype=O.NODE_DTYPE)
         p_end = np.ascontiguousarray(e0.particles(), dtype=O.PARTICLE_DTYPE)
         last_scan = scans[a.warmup + a.steps - 1]
-        if a.no_cpu_baseline or world > 1:
+        if a.no_cpu_baseline:
             _, visits, valid = O.score_kd(tree_end, p_end[:128], last_scan, stats=True)
             vbar, bvalid = visits / max(valid, 1), valid / 128
         else:
@@ -460,10 +528,13 @@ def main():
                                "that found their cell's row, redescents = queries that went on generically"
                                % (FIRST_FRAME, FIRST_FRAME + a.warmup + a.steps - 1)},
             "cells": dict(cell_stats, kernel_ms=plan_ms,
-                          note="lattice-cell rows of the LAST timed launch (pfslam_cell_stats, csrc/kd_cells.hip.inc): cells under the waves' "
-                               "beam-end boxes, one row per cell = the few nodes of the cell's first descent that can be nearest for some "
-                               "query of the cell (+ re-descent candidates); kernel_ms = k_group_box + k_cells_mark + k_cell_rows, which "
-                               "run before the scan-match kernel") if cell_stats["rows"] else None,
+                          per_update={k: cell_stats[k] / max(cell_stats["updates"], 1.0) for k in ("walked_from_root", "extended", "reused", "claimed")},
+                          note="persistent lattice-cell rows (pfslam_cell_stats, csrc/kd_cells.hip.inc) at the end of the timed window: cells "
+                               "claimed since the last wipe (one 384-byte record each), live rows (one per sub-cell), and since the wipe: cells "
+                               "walked from the root (once each), extensions (a link of the cell had gained a node in a frame's insert: a few "
+                               "hops, rows re-cut), looks that found a cell unchanged = reused, per_update = the same per k_cells_update.  "
+                               "kernel_ms = what this stream spends between the pose boxes and the scan-match kernel (waiting for the "
+                               "previous frame's map update + k_cells_update; marking and the walks of new cells run on streams of their own)") if cell_stats["rows"] else None,
             "plan": None if cell_stats["rows"] else dict(plan_stats, kernel_ms=plan_ms,
                          note="shared-prefix plan of the LAST timed launch (pfslam_plan_stats): one planning lane per (wave, beam) walks "
                               "the root path common to the wave's 64 queries and keeps only the nodes that can be nearest for some "
@@ -473,7 +544,7 @@ def main():
                           "(mean); peak = wave-gather rate of this chip measured in this process (pfslam_ubench_gather: cache-resident "
                           "table, 8 waves/SIMD) x 1024 B; frac_of_nominal_peak prices the same bytes against CUs x 64 B/clk x clock.  "
                           "The cell-row kernel of round 3 replaced the per-query tree walk by a handful of row slots per query, and what "
-                          "binds it now is VALU issue (pmc.valu_issue_frac ~ 1): `frac` says how much of the gather path it still uses, "
+                          "binds it now is the vector ALUs and the gather path together (pmc.valu_busy_measured, pmc.ta_busy): `frac` says how much of the gather path it still uses, "
                           "not how far it is from its own ceiling",
             "ubench": dict(ub, note="the measured rate is what the same gather instruction sustains on this box, wave-uniform addresses"),
             "pmc": None if not pmc else {
@@ -483,7 +554,18 @@ def main():
                 "ta_busy": (avgp["TA_TA_BUSY_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_TA_BUSY_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
                 "ta_cycles_frac": (avgp["TA_BUFFER_TOTAL_CYCLES_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_BUFFER_TOTAL_CYCLES_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
                 "valu_insts_per_simd_cycle": ((avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
-                "valu_issue_frac": (4.0 * (avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
+                "valu_issue_frac_if_4_cycles_each": (4.0 * (avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
+                # MEASURED busy cycles (round 4): SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends executing vector ALU instructions
+                # (rocprofiler's VALUBusy = 4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles); cycles = that pass's own kernel time x the measured clock
+                "valu_busy_measured": pmc_busy(pmc, avgp, "SQ_ACTIVE_INST_VALU", 4.0 * ub["cus"], clock_ghz, quad=True),
+                "vmem_issue_busy_measured": pmc_busy(pmc, avgp, "SQ_ACTIVE_INST_VMEM", 4.0 * ub["cus"], clock_ghz, quad=True),
+                "scalar_busy_measured": pmc_busy(pmc, avgp, "SQ_ACTIVE_INST_SCA", 4.0 * ub["cus"], clock_ghz, quad=True),
+                "sq_busy_measured": pmc_busy(pmc, avgp, "SQ_BUSY_CYCLES", 32.0, clock_ghz, quad=False),
+                "wave_cycles_waiting": (avgp["SQ_WAIT_ANY"] / avgp["SQ_WAVE_CYCLES"]) if avgp.get("SQ_WAIT_ANY") and avgp.get("SQ_WAVE_CYCLES") else None,
+                "valu_insts_by_type": {k[len("SQ_INSTS_VALU_"):].lower(): avgp[k] for k in sorted(avgp) if k.startswith("SQ_INSTS_VALU_")} or None,
+                # the line's gather fraction again, from profiles/ alone: every wave gather the counter saw as a 16-byte one, over the
+                # kernel time of the same file, against the gather rate measured live in this process
+                "frac_from_pmc_only": (ta_wf * 1024.0 / (pmc.get("kernel_ms") * 1e-3) / 1e9 / peak_measured) if ta_wf and pmc.get("kernel_ms") else None,
                 "hbm": None if traffic is None else {"bytes_per_launch": traffic, "achieved": traffic / kern_s / 1e9, "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS},
                 "note": "rocprofv3 PMC passes of `python bench.py --no-cpu-baseline` (tools/profile_round.sh), averaged over the TIMED "
@@ -492,9 +574,10 @@ def main():
                         "correction of MI355X_MICROARCH.md) -- the map records are cache resident, compulsory HBM traffic is ~20 B per "
                         "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement; the census "
                         "also counts the parent-index reads of the generic tail, global loads a BUFFER counter does not see); "
-                        "valu_issue_frac = 4 cycles x VALU wave-instructions per SIMD / kernel cycles: the share of its issue cycles "
-                        "a SIMD spends on vector ALU instructions of this kernel (the cell-row kernel runs with this and ta_busy both "
-                        "at 0.8-0.9: see DESIGN.md section 4)"},
+                        "valu_busy_measured = 4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles (the counter is in quad-cycles: rocprofiler's VALUBusy), "
+                        "the share of a SIMD's cycles spent executing vector ALU instructions -- MEASURED; valu_issue_frac_if_4_cycles_each "
+                        "is the round-3 estimate (every VALU instruction priced at 4 cycles) kept beside it; sq_busy_measured = "
+                        "SQ_BUSY_CYCLES / 32 shader engines x XCDs / cycles"},
             "alg_equiv": {"bytes_per_eval": alg_bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                           "GBs": alg_bytes_per_eval * n_local / kern_s / 1e9,
                           "note": "SURVEY 8d's algorithmic node bytes (B_valid x V x 32 B + 20 B): served from L1/L2, "
@@ -529,6 +612,10 @@ def main():
                                             "order + scan-match + reduce/min/max + weights + Neff (ICP runs under it); map = device chain incl. the "
                                             "insert of the new walls, kept on the main stream while the phases are timed (it runs on the aux "
                                             "stream otherwise); resample = the five gated launches, averaged over all frames")
+    if out is not None and hasattr(eng, "balance_builds"):
+        out["balance"] = {"host_builds_on_rank0": eng.balance_builds, "broadcasts": eng.balance_broadcasts,
+                          "note": "KDTree::Balance once per node: rank 0 re-builds the map on the host, the device arrays (28 B per node) "
+                                  "are broadcast, the other ranks adopt them (include/pfslam.h, pfslam_shard_balance_*)"}
     if out is not None:
         if world == 1 and not a.no_cpu_baseline:
             import oracle_lib as O

@@ -25,7 +25,7 @@ SYMBOLS = [
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
     "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads",
-    "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
+    "pfslam_time_score_grid", "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
 ]
 
 
@@ -96,6 +96,7 @@ def load():
     L.pfslam_shard_score.argtypes = [vp]
     L.pfslam_shard_weights.argtypes = [vp]
     L.pfslam_shard_finish.argtypes = [vp]
+    L.pfslam_time_score_grid.argtypes = [vp, i32, vp, vp]
     L.pfslam_set_shard_balance.argtypes = [vp, i32]
     L.pfslam_shard_balance_due.argtypes = [vp, i32, vp, vp]
     L.pfslam_shard_balance_build.argtypes = [vp, i32]
@@ -278,6 +279,11 @@ class PfSlam:
         fit = np.empty(self.n, np.float32)
         _chk(self.L.pfslam_score_kd(self._h, _p(fit)), "pfslam_score_kd")
         return fit
+
+    def time_score_grid(self, iters):
+        a, b = C.c_float(), C.c_float()
+        _chk(self.L.pfslam_time_score_grid(self._h, iters, C.byref(a), C.byref(b)), "pfslam_time_score_grid")
+        return a.value, b.value
 
     def time_score_kd(self, iters):
         ms = C.c_float()

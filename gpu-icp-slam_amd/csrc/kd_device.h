@@ -293,12 +293,13 @@ __device__ __forceinline__ float lidar_angle(int n)
     return fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f);
 }
 // the hot loops: the beam's angle and parts from a per-beam table (wave-uniform scalars), the heading's parts once per particle
+template <bool GUARD = true>
 __device__ __forceinline__ void clean_lidar_scan_parts(float angle, const AngleParts &A, float range, float theta, const AngleParts &T,
                                                        float &x, float &y)
 {
     const float rot = angle + theta;
     float s, c;
-    sincos_sum_spec(A, T, rot, s, c);
+    sincos_sum_spec<GUARD>(A, T, rot, s, c);
     x = range * c;
     y = range * s;
 }

@@ -118,9 +118,13 @@ PF_HD AngleParts angle_parts(float angle)
 // tests/test_oracle_pinning.py).  Headings are never normalised (kernel.cu:394 adds noise every frame), so the bound is part of
 // the definition.  The branch is taken by no lane in any realistic run: a compare and a skipped jump per end point.
 #define PF_SUM_THETA_MAX 1024.0f
+// GUARD false: the caller knows every heading it will see is below the bound (the scan-match kernel of the cell rows, told by the
+// host: the direct form's registers cost that kernel two of its eight waves per SIMD and 12 % of its time -- 79 instead of 60 VGPRs,
+// 0.488 instead of 0.433 ms per scoring pass, tools/experiments/r04/ab_big_theta.sh -- although no lane ever takes the branch).
+template <bool GUARD = true>
 PF_HD void sincos_sum_spec(const AngleParts &A, const AngleParts &T, float rot, float &s, float &c)
 {
-    if (!(fabs(T.a) < (double)PF_SUM_THETA_MAX)) { // (a NaN heading too)
+    if (GUARD && !(fabs(T.a) < (double)PF_SUM_THETA_MAX)) { // (a NaN heading too)
         sincosf_spec(rot, s, c);
         return;
     }

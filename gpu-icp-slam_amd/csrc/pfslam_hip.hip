@@ -70,7 +70,8 @@ struct HostHeader {
     int64_t stats[2];
     int32_t seq; // ticket of the frame that wrote this slot
     float cloud_sigma; // spread of the particle cloud as the frame's lane order saw it (m; max of x, y, reach x heading)
-    int32_t pad[14];
+    float theta_max;   // largest |heading| among the frame's particles (inf: a NaN among them); 0 when the pass made no pose boxes
+    int32_t pad[13];
 };
 static_assert(sizeof(HostHeader) == 128, "HostHeader is two 64-byte lines");
 #define PF_HDR_SLOTS 4 /* header / scan staging slots: frames in flight + 1 (PF_MAX_LAG + 2) */
@@ -150,7 +151,7 @@ struct pfslam_handle {
     // device, there is no idle gap between frames.  Any other entry point settles the frames in flight first (settle()).
     HostHeader *h_hdr = nullptr, *hdr_dev = nullptr; // PF_HDR_SLOTS pinned headers and their device view
     float *h_scan = nullptr;                         // PF_HDR_SLOTS pinned scan staging buffers
-    struct Frame { int seq, frame, kind; };          // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once)
+    struct Frame { int seq, frame, kind; bool boxes = false; }; // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once); boxes: its scoring pass made pose boxes (theta_max of its header is this frame's)
     std::deque<Frame> in_flight;
     int seq = 0; // tickets handed out
     int cur_seq = 0, cur_frame = 0; // the frame being enqueued (frame_front .. frame_tail)
@@ -207,7 +208,12 @@ struct pfslam_handle {
     // spread of the cloud (k_cell_count -> frame header -> here, one frame late; set_particles estimates it on the host): the cell rows'
     // marking pass costs the AREA of the waves' beam-end boxes in lattice cells, so a wide cloud is scored with the round-2 plan
     float cloud_sigma = 0.0f;
-    float *d_sigma = nullptr;
+    float *d_sigma = nullptr; // [0] spread  [1] max |heading| (k_group_box)
+    // upper bound of |heading| over the particles, for the choice of the scan-match kernel's instantiation (sincos_sum_spec<GUARD>): exact
+    // from set_particles, + 0.1 per dispersion (three draws of at most 6 sigma x 0.01 rad ... generously), + |d theta| per odometry
+    // shift, replaced by the device's own maximum + 1 whenever a frame's header comes in
+    float theta_bound = 0.0f, theta_shift = 0.0f;
+    int theta_shift_seq = 0;
     bool cells_suspended = false;  // the list / pool overflowed twice in a row: round-2 plan until the next upload_tree
     int cells_full_frame = -1;
     bool balance_external = false; // multi-GPU: ONE rank of the node re-balances, the others adopt its arrays (pfslam_set_shard_balance)
@@ -268,11 +274,12 @@ __global__ void k_beam_angles(pf::BeamParts *__restrict__ beams, int nb)
     const pf::AngleParts p = pf::angle_parts(angle);
     beams[j] = pf::BeamParts{p.c, p.s, p.a, angle, 0.0f};
 }
+template <bool GUARD = true>
 __device__ __forceinline__ void beam_end_point(const pf::BeamParts *__restrict__ beams, int j, float range, float theta, const pf::AngleParts &T,
                                                float &x, float &y)
 {
     const pf::BeamParts bp = beams[j]; // wave-uniform: scalar loads
-    pf::clean_lidar_scan_parts(bp.angle, pf::AngleParts{bp.c, bp.s, bp.a}, range, theta, T, x, y);
+    pf::clean_lidar_scan_parts<GUARD>(bp.angle, pf::AngleParts{bp.c, bp.s, bp.a}, range, theta, T, x, y);
 }
 
 // ---- A5: scan-match score (EvaluateParticleKD / kernEvaluateParticlesKD, kernel.cu:1198-1308)
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
 // pose bounding box of every group of 64 lanes (= one wave of the score kernel)
 __global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, const float *__restrict__ py, const float *__restrict__ pth,
                                                   int n, const int *__restrict__ order, pf::KdGroupBox *__restrict__ box,
-                                                  pf::AngleParts *__restrict__ parts)
+                                                  pf::AngleParts *__restrict__ parts, float *__restrict__ sigma)
 {
     const int slot = blockIdx.x * 64 + threadIdx.x;
     const bool in = slot < n;
@@ -337,6 +344,8 @@ __global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, 
         pf::KdGroupBox b{xlo, xhi, ylo, yhi, tlo, thi, min(64, n - (int)blockIdx.x * 64), 0};
         if (bad != 0ull) b.xlo = b.xhi = NAN;
         box[blockIdx.x] = b;
+        // largest |heading| of the cloud (non-negative floats order like their bit patterns; a NaN pose counts as infinity)
+        atomicMax((int *)&sigma[1], __float_as_int(bad != 0ull ? INFINITY : fmaxf(fabsf(tlo), fabsf(thi))));
         if (parts) parts[blockIdx.x] = pf::angle_parts(0.5f * (b.tlo + b.thi)); // of beam_box's centre heading: once per group here
 
     }
@@ -576,7 +585,10 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     const float dev_x = sqrtf(block_sum_256(vx, red) * inv), dev_y = sqrtf(block_sum_256(vy, red) * inv);
     const float dev_t = sqrtf(block_sum_256(vt, red) * inv) * reach;
     const float D = (float)(1 << bits), half = 0.5f * D, top = D - 1.0f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sigma_out[0] = fmaxf(fmaxf(dev_x, dev_y), dev_t); // -> frame header -> host (organisation of the next pass)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sigma_out[0] = fmaxf(fmaxf(dev_x, dev_y), dev_t); // -> frame header -> host (organisation of the next pass)
+        sigma_out[1] = 0.0f;                              // max |heading|: k_group_box, behind this kernel
+    }
     const float e = fmaxf(6.4f / D * fmaxf(fmaxf(dev_x, dev_y), dev_t), 2.5e-4f);
     const float cx = 1.0f / e, cy = 1.0f / e, ct = reach / e;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1167,6 +1179,10 @@ extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, 
         }
         const double sg = std::max(std::max(std::sqrt(v[0] / ns), std::sqrt(v[1] / ns)), std::sqrt(v[2] / ns) * h->scan_reach);
         h->cloud_sigma = std::isfinite(sg) ? (float)sg : 0.0f;
+        float tb = 0.0f;
+        for (int i = 0; i < n; i++) tb = p[i].theta == p[i].theta ? std::max(tb, fabsf(p[i].theta)) : INFINITY;
+        h->theta_bound = tb;
+        h->theta_shift = 0.0f;
     }
     HIPCHK(hipMemcpyAsync(h->x, &tmp[0], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->y, &tmp[n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -1318,6 +1334,7 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
     hipLaunchKernelGGL(k_motion, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->w, h->wm,
                        h->n, frame, h->goff);
     HIPCHK(hipGetLastError());
+    h->theta_bound += 0.1f;
     return 0;
 }
 
@@ -1339,6 +1356,8 @@ extern "C" int pfslam_shift_particles(pfslam_handle *h, const float delta[3])
     if (!h || !delta) return fail("pfslam_shift_particles: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(join_map(h)); // the map update a frame left on the aux stream reads the pose
+    h->theta_shift = delta[2] == delta[2] ? h->theta_shift + fabsf(delta[2]) : INFINITY; // (headers of frames enqueued before this do not know of it)
+    h->theta_shift_seq = h->seq;
     hipLaunchKernelGGL(k_shift, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, delta[0], delta[1], delta[2], h->pose);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1506,7 +1525,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_marked, 0));
             h->mark_on_aux = false;
         }
-        hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box, h->group_parts);
+        hipLaunchKernelGGL(k_group_box, dim3(groups), dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, order, h->group_box, h->group_parts, h->d_sigma);
     }
     hipEvent_t t_a = nullptr, t_b = nullptr;
     if (h->timing && !census) {
@@ -1567,8 +1586,12 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
 #define PF_CELLS_ARGS grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc, kd_view(h), geo, \
                       (const unsigned *)h->cell_tab, (const uint4 *)h->cell_pool, (const int *)h->cell_state, order, direct
             // a census replay BEHIND an accumulating pass must not add its (identical) sums a second time
-            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : 0, cen);
-            else hipLaunchKernelGGL((k_score_kd_cells<false>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : 0, (pf::KdCensus *)nullptr);
+            // no heading anywhere near the bound of the angle-addition sincos (the host's running bound, refreshed from every frame's
+            // header): the instantiation without the direct form -- 60 instead of 79 VGPRs, 8 instead of 6 waves per SIMD
+            const bool guard = !(h->theta_bound < 0.5f * PF_SUM_THETA_MAX) || h->own_global; // (a shard imports particles at every resample: always guarded)
+            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : 0, cen);
+            else if (guard) hipLaunchKernelGGL((k_score_kd_cells<false, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : 0, (pf::KdCensus *)nullptr);
+            else hipLaunchKernelGGL((k_score_kd_cells<false, false>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : 0, (pf::KdCensus *)nullptr);
 #undef PF_CELLS_ARGS
         } else if (use_plan) {
             if (cen)

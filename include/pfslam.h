@@ -290,6 +290,9 @@ int pfslam_plan_stats(pfslam_handle *h, double out[10]);
  * twice within 16 frames (a cloud too wide for the table), the round-2 plan scores until the map is replaced or re-balanced.
  * [0 .. 13] are zero when the last scoring pass did not use cell rows. */
 int pfslam_cell_stats(pfslam_handle *h, double out[16]);
+/* mean duration (ms) of the 2-D scan-match kernel alone and of the whole 2-D scoring pass (kernel + partial sums + min / max / argmax +
+ * weights) over `iters` launches each, HIP events on the handle's stream */
+int pfslam_time_score_grid(pfslam_handle *h, int iters, float *ms_kernel, float *ms_pass);
 int pfslam_set_variant(pfslam_handle *h, int variant);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */

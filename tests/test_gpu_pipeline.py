@@ -139,3 +139,34 @@ def test_kd_and_grid_frames_alternate_without_settling(pkg):
     for fld in ("x", "y", "theta", "w"):
         assert (bits(got[fld]) == bits(want[fld])).all(), fld
     h.close(); o.close()
+
+
+def test_headings_beyond_the_angle_addition_bound_in_the_frame_loop(pkg):
+    """The scan-match kernel of the cell rows runs WITHOUT the direct form of CleanLidarScan's cos / sin while the host's bound on
+    |heading| is below 512 rad (csrc/pf_math.h, sincos_sum_spec<GUARD>; the bound follows set_particles, the odometry shifts and
+    every frame's header).  Headings pushed beyond 1024 rad -- by a shift between two frames in flight, and by set_particles -- must
+    switch the guarded kernel in: poses, maps and particles stay bit-identical to the oracle."""
+    assert pkg.device_count() > 0
+    n, nframes = 5000, 14
+    segs, frames = pkg.synth.corridor_sequence(nframes, seed=13)
+    o = O.Slam(n, kd_capacity=1 << 16)
+    h = pkg.PfSlam(n, kd_capacity=1 << 16)
+    h.set_variant(3)    # the cell rows whatever the cloud's spread
+    for f, (_, scan) in enumerate(frames, start=1):
+        if f == 6:      # between two enqueued frames: + 164 full turns, heading ~ 1030 rad, the scans still fit
+            d = np.array([0.0, 0.0, 164 * 2 * np.pi], np.float32)
+            o.shift_particles(d); h.shift_particles(d)
+        if f == 10:     # and back below the bound through set_particles
+            p = o.particles().copy()
+            p["theta"] = (p["theta"] - np.float32(164 * 2 * np.pi)).astype(np.float32)
+            o.set_particles(p); h.set_particles(p)
+        o.step(f, scan); h.step(f, scan)
+        if f in (5, 7, 9, 11, 14):
+            assert (bits(h.pose) == bits(o.pose)).all(), f
+    st = h.cell_stats()
+    assert st["rows"] > 0      # the cell rows were in use
+    assert h.map().tobytes() == o.tree().tobytes()
+    got, want = h.particles(), o.particles()
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[fld]) == bits(want[fld])).all(), fld
+    h.close(); o.close()

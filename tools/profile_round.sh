@@ -13,7 +13,13 @@ mkdir -p $OUT/summary
 CMD="python bench.py --no-cpu-baseline $ARGS"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/bench_kt.log 2>&1
 grep '^{' $OUT/bench_kt.log > $OUT/summary/bench_under_kernel_trace.json
-for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum"; do
+# round 4: measured busy cycles of the vector ALUs (SQ_ACTIVE_INST_VALU is in quad-cycles: rocprofiler's own VALUBusy = 4 x it / SIMDs /
+# cycles), the SQ's busy cycles, and the fp64 / fp32 / integer split of the VALU instructions; a pass whose counter does not exist on
+# this part fails on its own and leaves the others alone
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum" \
+         "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT" \
+         "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32" \
+         "SQ_LEVEL_WAVES" "SQ_INST_CYCLES_VALU" "SQ_IFETCH SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32"; do
   N=$(echo $C | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -o pmc -- $CMD > $OUT/bench_pmc_$N.log 2>&1
 done

@@ -774,7 +774,7 @@ static int create_impl(pfslam_handle *h)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         static const bool prio = !(getenv("PFSLAM_AUX_PRIO") && atoi(getenv("PFSLAM_AUX_PRIO")) == 0);
         HIPCHK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio ? hi : lo));
-        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, prio ? hi : lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, lo)); // (beside the scan-match kernel: it must not get in its way)
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
         HIPCHK(hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scored, hipEventDisableTiming));
@@ -1380,6 +1380,9 @@ static int score_chunks(const pfslam_handle *h)
 }
 
 // ---- persistent lattice-cell rows: host side ---------------------------------------------------------------------------------
+#define PF_CELLS_WALK_GRID 32 /* ... of k_cells_update<false>: it runs beside the scan-match kernel, finds a handful of new cells (at the list's end:
+                                 one or two waves) and otherwise only reads record headers -- 512 workgroups with 47 KB of LDS each, on a high-priority
+                                 stream, cost that kernel anything between 0 and 80 us from run to run */
 #define PF_CELLS_GRID 512 /* workgroups (one wave each) of k_cells_update, grid-stride over the records: two fit a CU (78 KB of LDS each), so 512
                              are resident together -- 2048 of them queued through the few free places while the first 476 worked (56 us) */
 struct CellArgs { unsigned *tab; int *list, *cs; uint4 *pool; int *rec; };
@@ -1553,7 +1556,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             HIPCHK(hipEventRecord(h->ev_marked, st));
             h->mark_on_aux = true;
             if (h->map_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_map, 0)); // the tree as the previous frame's insert left it, and behind that frame's k_cells_update
-            hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
+            hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_WALK_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
             HIPCHK(hipEventRecord(h->ev_walked, st));
             h->walk_pending = true;
         }

@@ -1388,16 +1388,20 @@ static int score_chunks(const pfslam_handle *h)
 #define PF_CELLS_GRID 512 /* workgroups (one wave each) of k_cells_update, grid-stride over the records: two fit a CU (78 KB of LDS each), so 512
                              are resident together -- 2048 of them queued through the few free places while the first 476 worked (56 us) */
 struct CellArgs { unsigned *tab; int *list, *cs; uint4 *pool; int *rec; };
-__global__ void k_cells_reset(int *cs)
+__global__ void k_cells_reset(int *cs, int list_cap, int pool_cap)
 {
-    if (threadIdx.x < PF_CS_WORDS) cs[threadIdx.x] = threadIdx.x == PF_CS_FLAGS ? PF_CF_NEED_ORIGIN : 0;
+    if (threadIdx.x < PF_CS_WORDS)
+        cs[threadIdx.x] = threadIdx.x == PF_CS_FLAGS ? PF_CF_NEED_ORIGIN : threadIdx.x == PF_CS_LIST_CAP ? list_cap : threadIdx.x == PF_CS_POOL_CAP ? pool_cap : 0;
 }
 // table, records and pool start over (enqueued; the caller has joined the aux stream).  105 MB of memset: rare -- a new map, a
 // re-balance (an 11 ms stall of its own), an exhausted list / pool, a cloud that has left the middle of the window.
 static int cells_wipe(pfslam_handle *h)
 {
     HIPCHK(hipMemsetAsync(h->cell_tab, 0, (size_t)PF_CELL_WIN * PF_CELL_WIN * 4, h->stream));
-    hipLaunchKernelGGL(k_cells_reset, dim3(1), dim3(64), 0, h->stream, h->cell_state);
+    // (the capacities in use: the allocations, unless a test of the overflow paths asks for less)
+    static const int list_cap = getenv("PFSLAM_CELL_LIST_CAP") ? std::min(std::max(atoi(getenv("PFSLAM_CELL_LIST_CAP")), 64), PF_CELL_LIST_CAP) : PF_CELL_LIST_CAP;
+    static const int pool_cap = getenv("PFSLAM_CELL_POOL_CAP") ? std::min(std::max(atoi(getenv("PFSLAM_CELL_POOL_CAP")), 64), PF_CELL_POOL_CAP) : PF_CELL_POOL_CAP;
+    hipLaunchKernelGGL(k_cells_reset, dim3(1), dim3(64), 0, h->stream, h->cell_state, list_cap, pool_cap);
     HIPCHK(hipGetLastError());
     h->cells_wipe_pending = false;
     h->cells_wipe_seq = h->seq;
@@ -1836,7 +1840,7 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
     HIPCHK(hipMemcpyAsync(cs, h->cell_state, sizeof(cs), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int rows = cs[PF_CS_ROWS];
-    out[0] = std::min(cs[PF_CS_COUNT], PF_CELL_LIST_CAP);
+    out[0] = std::min(cs[PF_CS_COUNT], cs[PF_CS_LIST_CAP]);
     out[1] = rows;
     out[2] = rows ? (double)cs[PF_CS_N1] / rows : 0.0;
     out[3] = rows ? (double)cs[PF_CS_N2] / rows : 0.0;

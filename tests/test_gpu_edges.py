@@ -266,7 +266,10 @@ def test_differential_fuzz_of_the_frame_loop():
     # and once more with the shared-prefix plan of the score kernel on at EVERY particle count (by default it starts at ~6 k
     # particles): tiny waves, partly filled waves, NaN / Inf scans and clouds at the map edge all go through the planning kernel
     # (lattice-cell rows -- the SLAM step's own maps lie on the lattice --, then the round-2 shared-prefix plan)
-    for extra, seed in (({}, "11"), ({"PFSLAM_VARIANT": "4"}, "12")):
+    # ... and with the persistent cell rows forced on and their list / pool capacities cut to a few hundred entries: the overflow paths
+    # (cells left without rows, wipes asked for in the frame header, suspension after the second overflow) change no result
+    for extra, seed in (({}, "11"), ({"PFSLAM_VARIANT": "4"}, "12"),
+                        ({"PFSLAM_VARIANT": "3", "PFSLAM_CELL_LIST_CAP": "200", "PFSLAM_CELL_POOL_CAP": "1500"}, "13")):
         env = dict(os.environ, PFSLAM_PLAN_MIN_N="1", **extra)
         out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_step.py"), "15", seed], capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

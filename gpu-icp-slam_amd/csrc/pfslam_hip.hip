@@ -234,6 +234,7 @@ struct pfslam_handle {
     hipStream_t cstream = nullptr;  // marking + walks of the new cells in the frame loops: beside the ICP solve, under the scan-match kernel
     hipEvent_t ev_walked = nullptr; // ... finished: the frame's insert (k_test_new changes the tree they read) waits for it
     bool walk_pending = false;
+    bool cells_snap = false;       // this frame's k_cells_update<true> may run beside the next frame's marking pass: records below the walk pass's snapshot only
     pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
 };
@@ -1416,8 +1417,16 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
 {
     if (!h->cell_tab || h->cells_wipe_pending) return 0; // (a pending wipe: the records belong to a map that is gone)
     const CellGeom geo{h->cfg.map_res_x, h->cfg.map_res_y, 1.0f / h->cfg.map_res_x, 1.0f / h->cfg.map_res_y};
+    // Every PF_CELLS_RECUT_EVERY-th update cuts EVERY cell's rows again, into a pool that starts over: rows that outgrow their place
+    // move to the pool's end, and after ~20 frames the rows a wave gathers together no longer sit together -- the scan-match kernel,
+    // with nothing running beside it, went from 0.37 to 0.40-0.42 ms between the 10th and the 20th frame after a wipe (the round-3
+    // build, which cut everything every frame, stayed flat).  A cut needs no walk: the records hold the candidates.
+    static const int recut_every = getenv("PFSLAM_CELLS_RECUT_EVERY") ? atoi(getenv("PFSLAM_CELLS_RECUT_EVERY")) : 8;
+    const int recut = recut_every > 0 && h->cells_passes > 0 && h->cells_passes % recut_every == 0 ? 1 : 0;
+    if (recut) HIPCHK(hipMemsetAsync(h->cell_state + PF_CS_POOL, 0, 4, st));
     hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,
-                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15));
+                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15), recut, h->cells_snap ? 1 : 0);
+    h->cells_snap = false;
     HIPCHK(hipGetLastError());
     h->cells_passes++;
     return 0;
@@ -1543,7 +1552,8 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         HIPCHK(hipEventRecord(t_a, h->stream));
     }
     const CellArgs ca{h->cell_tab, h->cell_list, h->cell_state, h->cell_pool, h->cell_rec};
-    if (use_cells) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
+    static const bool no_async_mark = getenv("PFSLAM_NO_ASYNC_MARK") && atoi(getenv("PFSLAM_NO_ASYNC_MARK")) != 0; // EXPERIMENT
+    if (use_cells && !(no_async_mark && !cells_sync)) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
         hipStream_t st = h->stream;
         if (!cells_sync) {
             // On a stream of their own.  The marking pass needs the pose boxes and the scan only, and claims nothing but table words that
@@ -1565,6 +1575,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_WALK_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
             HIPCHK(hipEventRecord(h->ev_walked, st));
             h->walk_pending = true;
+            h->cells_snap = true;
         }
         HIPCHK(hipGetLastError());
     }

@@ -208,7 +208,7 @@ struct pfslam_handle {
     // spread of the cloud (k_cell_count -> frame header -> here, one frame late; set_particles estimates it on the host): the cell rows'
     // marking pass costs the AREA of the waves' beam-end boxes in lattice cells, so a wide cloud is scored with the round-2 plan
     float cloud_sigma = 0.0f;
-    float *d_sigma = nullptr; // [0] spread  [1] max |heading| (k_group_box)
+    float *d_sigma = nullptr; // [0] spread  [2 .. 65] partial maxima of |heading| (k_group_box)
     // upper bound of |heading| over the particles, for the choice of the scan-match kernel's instantiation (sincos_sum_spec<GUARD>): exact
     // from set_particles, + 0.1 per dispersion (three draws of at most 6 sigma x 0.01 rad ... generously), + |d theta| per odometry
     // shift, replaced by the device's own maximum + 1 whenever a frame's header comes in
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(64) void k_group_box(const float *__restrict__ px, 
         if (bad != 0ull) b.xlo = b.xhi = NAN;
         box[blockIdx.x] = b;
         // largest |heading| of the cloud (non-negative floats order like their bit patterns; a NaN pose counts as infinity)
-        // (a look first: 1563 atomics on one word took this kernel from 6 to 21 us; almost every group is below the running maximum)
+        // (spread over 64 words: 1563 atomics on ONE word took this kernel from 6 to 21 us; the header's writer takes their maximum)
         const float tmax = bad != 0ull ? INFINITY : fmaxf(fabsf(tlo), fabsf(thi));
-        if (tmax > __hip_atomic_load(&sigma[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((int *)&sigma[1], __float_as_int(tmax));
+        atomicMax((int *)&sigma[2 + (blockIdx.x & 63)], __float_as_int(tmax));
         if (parts) parts[blockIdx.x] = pf::angle_parts(0.5f * (b.tlo + b.thi)); // of beam_box's centre heading: once per group here
 
     }
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(256) void k_cell_count(const float *__restrict__ x,
     const float D = (float)(1 << bits), half = 0.5f * D, top = D - 1.0f;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sigma_out[0] = fmaxf(fmaxf(dev_x, dev_y), dev_t); // -> frame header -> host (organisation of the next pass)
-        sigma_out[1] = 0.0f;                              // max |heading|: k_group_box, behind this kernel
     }
+    if (blockIdx.x == 0 && threadIdx.x < 64) sigma_out[2 + threadIdx.x] = 0.0f; // max |heading|, 64 partial maxima: k_group_box, behind this kernel
     const float e = fmaxf(6.4f / D * fmaxf(fmaxf(dev_x, dev_y), dev_t), 2.5e-4f);
     const float cx = 1.0f / e, cy = 1.0f / e, ct = reach / e;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -837,8 +837,8 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->d_count, 4));
     CHK(dalloc(&h->wall_leaf, (size_t)h->max_wall));
     CHK(dalloc(&h->kd_state, 4));
-    CHK(dalloc(&h->d_sigma, 4));
-    HIPCHK(hipMemsetAsync(h->d_sigma, 0, 16, h->stream));
+    CHK(dalloc(&h->d_sigma, 2 + 64));
+    HIPCHK(hipMemsetAsync(h->d_sigma, 0, (2 + 64) * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->kd_state, 0, 16, h->stream));
     // headers and scan staging: pinned, coherent (the device writes a header while the stream keeps running, the host may poll it)
     HIPCHK(hipHostMalloc((void **)&h->h_hdr, PF_HDR_SLOTS * sizeof(HostHeader), hipHostMallocCoherent | hipHostMallocMapped));

@@ -1571,7 +1571,13 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (!cells_sync) { // the new cells' walks from the root: records only, published behind this frame's insert
             HIPCHK(hipEventRecord(h->ev_marked, st));
             h->mark_on_aux = true;
-            if (h->map_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_map, 0)); // the tree as the previous frame's insert left it, and behind that frame's k_cells_update
+            // The tree as the previous frame's insert left it, and BEHIND that frame's k_cells_update -- always, not only while the host
+            // still has that map update down as unjoined: a getter between two frames (pfslam_get_trace books the frame as soon as its
+            // header is there, which k_test_new writes BEFORE k_cells_update runs) clears that flag, and the walk pass then ran beside the
+            // previous k_cells_update, which could pick up a record whose header the walk had written and whose candidates it had
+            // not (one diverging case in 12 000 of the differential fuzz with a look every third frame).  Waiting for an event that
+            // has fired -- or was never recorded -- costs nothing.
+            HIPCHK(hipStreamWaitEvent(st, h->ev_map, 0));
             hipLaunchKernelGGL(k_cells_update<false>, dim3(PF_CELLS_WALK_GRID), dim3(64), 0, st, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
             HIPCHK(hipEventRecord(h->ev_walked, st));
             h->walk_pending = true;

@@ -106,6 +106,13 @@ static bool parse(int argc, char **argv, Args &a)
 // ---- launcher: N copies of this binary, one per GPU ---------------------------------------------------------------
 static int launch(int argc, char **argv, const Args &a)
 {
+    // a rank without a GPU of its own would leave the others hanging in ncclCommInitRank: refuse up front (the children exec a fresh
+    // image, so looking at the device count here initialises nothing they inherit)
+    const int ndev = pfslam_device_count();
+    if (a.gpus > ndev) {
+        fprintf(stderr, "pfslam_mgpu: --gpus %d but only %d device(s) are visible: refusing to launch ranks\n", a.gpus, ndev);
+        return 2;
+    }
     char tmpl[] = "/tmp/pfslam_mgpu_XXXXXX";
     if (!mkdtemp(tmpl)) {
         perror("mkdtemp");
@@ -292,6 +299,14 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
     if (count <= 0) {
         fprintf(stderr, "[rank %d] empty shard: %ld particles over %d ranks\n", rank, G, world);
         return 1;
+    }
+    {
+        int ndev = 0;
+        HIP(hipGetDeviceCount(&ndev));
+        if (local_rank >= ndev) { // (started by torchrun or by hand with more ranks than devices)
+            fprintf(stderr, "[rank %d] local rank %d but only %d device(s) are visible: refusing to join (the other ranks would hang in ncclCommInitRank)\n", rank, local_rank, ndev);
+            return 2;
+        }
     }
     HIP(hipSetDevice(local_rank));
     ncclUniqueId id;

@@ -10,6 +10,11 @@ import oracle_lib as O
 pkg = importlib.import_module("gpu-icp-slam_amd")
 os.environ.setdefault("ORC_THREADS", str(min(64, os.cpu_count() or 1)))
 
+# python tests/fuzz_step.py --replay FILE : the case a diverging run saved (gpurun_out/fuzz_case.npz), stepped again with a look at every frame
+REPLAY = None
+if len(sys.argv) > 2 and sys.argv[1] == "--replay":
+    REPLAY = np.load(sys.argv[2], allow_pickle=True)
+    sys.argv = [sys.argv[0], "1e9", "1"]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
@@ -59,8 +64,10 @@ while time.time() < t_end:
     h.set_lag(lag)
     desc.update(lag=lag, stride=stride)
     ok = True
+    used = []
     for f, (_, scan) in enumerate(frames, start=1):
         scan = mutate(np.ascontiguousarray(scan[:nb]), rng)
+        used.append(scan)
         if drift and f == 2:
             p = O.make_particles(n, scale / 2 - 0.3, -scale / 2 + 0.2, 1.0)
             o.set_particles(p); h.set_particles(p)
@@ -90,6 +97,8 @@ while time.time() < t_end:
             print("UNEXPECTED ERROR", desc, f, e); sys.exit(2)
         same = (tg == to) or (np.isnan(to["neff"]) and np.isnan(tg["neff"]) and {k: v for k, v in tg.items() if k != "neff"} == {k: v for k, v in to.items() if k != "neff"})
         if not same or not (bits(h.pose) == bits(o.pose)).all():
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_case.npz"), desc=np.array([desc], dtype=object), scans=np.array(used), drift=drift, frame=f)
             print("DIVERGED", desc, "frame", f, tg, to, h.pose, o.pose); sys.exit(1)
         frames_total += 1
     if not ok:

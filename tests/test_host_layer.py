@@ -232,3 +232,21 @@ def test_cpp_rccl_driver_world1_is_bit_identical_to_pfslam_step(tmp_path, pkg, p
     assert (tmp_path / "out.rank0.nodes").read_bytes() == h.map().tobytes()
     assert (np.array(d["config"]["pose"], np.float32).view(np.int32) == h.pose.view(np.int32)).all()
     h.close()
+
+
+@pytest.mark.gpu
+def test_mgpu_and_bench_refuse_more_ranks_than_devices(tmp_path):
+    """A rank without a GPU of its own would leave the others hanging in ncclCommInitRank: `pfslam_mgpu --gpus N` and `bench.py --gpus N`
+    refuse N > visible devices with a clear message instead."""
+    import importlib
+    pkg = importlib.import_module("gpu-icp-slam_amd")
+    n = pkg.device_count() + 3
+    (tmp_path / "map.nodes").write_bytes(b"\0" * 64)
+    (tmp_path / "scans.f32").write_bytes(b"\0" * 1081 * 4 * 4)
+    r = subprocess.run([os.path.join(HOST, "pfslam_mgpu"), "--gpus", str(n), str(tmp_path / "map.nodes"), str(tmp_path / "scans.f32"), "100"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr, r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout), r.stderr[-500:]

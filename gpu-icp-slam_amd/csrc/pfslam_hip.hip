@@ -106,6 +106,7 @@ struct pfslam_handle {
     float *kz = nullptr, *kw = nullptr;
     std::vector<pfslam_node> h_nodes; // host mirror (topology + positions; w refreshed on demand)
     bool integral_w = true; // every map weight is an integer (true for every map the SLAM step itself produces)
+    float w_absmax = 113.0f; // largest |weight| the map can hold: of the uploaded map, or the clamp of the map update (113) if that is larger
     // scoring
     float *fit = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
@@ -1093,11 +1094,12 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     std::vector<float> z(n), w(n);
     // pass 1 (parallel): links in range, planar, integer weights, on the lattice of the config -- x == fl(k * res) bit for bit, the way
     // cell_to_point (ROUND_FRAC, kernel.cu:52) makes map points
-    std::atomic<int> bad{-1}, nonplanar{0}, nonintegral{0}, offlattice{0};
+    std::atomic<int> bad{-1}, nonplanar{0}, nonintegral{0}, offlattice{0}, wmax_bits{0};
     const float rx = h->cfg.map_res_x, ry = h->cfg.map_res_y, ix = 1.0f / rx, iy = 1.0f / ry;
     const float xmax = rx * (float)PF_LATTICE_KMAX, ymax = ry * (float)PF_LATTICE_KMAX;
     parallel_chunks(n, [&](int lo, int hi, int) {
         bool np = false, ni = false, ol = false;
+        float wm = 0.0f;
         for (int i = lo; i < hi; i++) {
             const pfslam_node &nd = nodes[i];
             if (nd.axis < 0 || nd.axis > 2 || nd.left < -1 || nd.left >= n || nd.right < -1 || nd.right >= n || nd.parent < -1 || nd.parent >= n) {
@@ -1111,6 +1113,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
             np |= nd.z != 0.0f;
             // |w| <= 2^13 keeps every partial sum of 1081 weights below 2^24, i.e. exact in any order
             ni |= !(nd.w == (float)(int)nd.w && fabsf(nd.w) <= 8192.0f);
+            wm = nd.w == nd.w ? std::max(wm, fabsf(nd.w)) : INFINITY;
             if (!ol) {
                 if (!(fabsf(nd.x) < xmax && fabsf(nd.y) < ymax)) ol = true; // |k| < 2^20 cells per axis (PF_LATTICE_KMAX); NaN fails
                 else {
@@ -1119,6 +1122,11 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
                            (ky * ry == nd.y || (ky + 1.0f) * ry == nd.y || (ky - 1.0f) * ry == nd.y));
                 }
             }
+        }
+        {
+            int cur = wmax_bits.load(), mine;
+            memcpy(&mine, &wm, 4);
+            while (mine > cur && !wmax_bits.compare_exchange_weak(cur, mine)) {}
         }
         if (np) nonplanar = 1;
         if (ni) nonintegral = 1;
@@ -1138,7 +1146,14 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     HIPCHK(hipMemcpyAsync(h->parent, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kz, z.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->kw, w.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    const int state[4] = {n, planar, integral ? 1 : 0, lattice ? 1 : 0}; // [1 .. 3]: for the ranks that adopt this tree (pfslam_shard_balance_adopt)
+    float wabs;
+    {
+        const int wb = wmax_bits.load();
+        memcpy(&wabs, &wb, 4);
+        wabs = std::max(wabs, PF_CLAMP_VAL); // the map update moves a weight by -1 / +4 and clamps to +-113: never beyond the larger of the two
+    }
+    // [1 .. 3]: for the ranks that adopt this tree (pfslam_shard_balance_adopt); [2]: 0 = weights not all integers, else their largest magnitude
+    const int state[4] = {n, planar, integral ? (int)std::min(wabs, 1e9f) : 0, lattice ? 1 : 0};
     HIPCHK(hipMemcpyAsync(h->kd_state, state, 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->h_nodes.assign(nodes, nodes + n);
@@ -1147,6 +1162,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n)
     h->mirror_stale = false;
     h->planar = planar;
     h->integral_w = integral;
+    h->w_absmax = wabs;
     h->lattice_ok = lattice;
     h->cells_wipe_pending = true; // rows of the previous map
     h->cells_suspended = false;
@@ -1434,7 +1450,7 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
 
 struct ShardPack;
 __global__ void k_reduce_partials_minmax(float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
-                                         const float *x, const float *y, const float *th, ShardPack *pack, int wipe);
+                                         const float *x, const float *y, const float *th, ShardPack *pack, int wipe, int p16);
 __global__ void k_shard_pack(const long long *stats, const float *x, const float *y, const float *th, int n, int goff, ShardPack *pack);
 __global__ void k_reduce_partials_minmax_wide(const float *partial, int n, int chunks, const int *order, float *fit, long long *stats);
 template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
@@ -1526,6 +1542,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     static const bool acc_enabled = getenv("PFSLAM_ACC_OUT") && atoi(getenv("PFSLAM_ACC_OUT")) != 0;
     const bool acc_out = acc_enabled && use_cells && h->integral_w && used > 1 && fuse_minmax && !census;
     const int direct = used > 1 ? 0 : 1;
+    // beam-chunk partials of the cell-row kernel as 16-bit integers: integer weights, and a chunk's sum cannot leave the range
+    const bool wide_reduce = used >= 256 && fuse_minmax && !shard_pack && h->goff == 0 && !acc_out;
+    static const bool p16_ok = !(getenv("PFSLAM_P16") && atoi(getenv("PFSLAM_P16")) == 0);
+    const bool p16 = p16_ok && use_cells && h->integral_w && used > 1 && fuse_minmax && !acc_out && !wide_reduce && (float)bpc * h->w_absmax <= 32767.0f;
     h->plan_valid = use_plan;
     h->cells_valid = use_cells;
     if (use_plan || use_cells) { // the pose boxes do not need the map: in front of the join
@@ -1615,9 +1635,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             // no heading anywhere near the bound of the angle-addition sincos (the host's running bound, refreshed from every frame's
             // header): the instantiation without the direct form -- 60 instead of 79 VGPRs, 8 instead of 6 waves per SIMD
             const bool guard = !(h->theta_bound < 0.5f * PF_SUM_THETA_MAX) || h->own_global; // (a shard imports particles at every resample: always guarded)
-            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : 0, cen);
-            else if (guard) hipLaunchKernelGGL((k_score_kd_cells<false, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : 0, (pf::KdCensus *)nullptr);
-            else hipLaunchKernelGGL((k_score_kd_cells<false, false>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : 0, (pf::KdCensus *)nullptr);
+            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : p16 ? 3 : 0, cen);
+            else if (guard) hipLaunchKernelGGL((k_score_kd_cells<false, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : p16 ? 3 : 0, (pf::KdCensus *)nullptr);
+            else hipLaunchKernelGGL((k_score_kd_cells<false, false>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : p16 ? 3 : 0, (pf::KdCensus *)nullptr);
 #undef PF_CELLS_ARGS
         } else if (use_plan) {
             if (cen)
@@ -1672,14 +1692,14 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (!h->stats_clean) CHK(launch_stats_reset(h, h->stream));
         h->stats_clean = false;
     }
-    if (used >= 256 && fuse_minmax && !shard_pack && h->goff == 0 && !acc_out) { // few particles, one beam per wave: 16 threads per particle
+    if (wide_reduce) { // few particles, one beam per wave: 16 threads per particle
         hipLaunchKernelGGL(k_reduce_partials_minmax_wide, dim3((h->n + 63) / 64), dim3(1024), 0, h->stream, h->partial, h->n, used, order,
                            h->fit, (long long *)h->stats);
         HIPCHK(hipGetLastError());
     } else if (used > 1 && fuse_minmax) {
         hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
                            acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th,
-                           shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0);
+                           shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0, p16 ? 1 : 0);
         HIPCHK(hipGetLastError());
     } else {
         if (used > 1) {

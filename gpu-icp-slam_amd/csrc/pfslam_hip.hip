@@ -1572,8 +1572,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         HIPCHK(hipEventRecord(t_a, h->stream));
     }
     const CellArgs ca{h->cell_tab, h->cell_list, h->cell_state, h->cell_pool, h->cell_rec};
-    static const bool no_async_mark = getenv("PFSLAM_NO_ASYNC_MARK") && atoi(getenv("PFSLAM_NO_ASYNC_MARK")) != 0; // EXPERIMENT
-    if (use_cells && !(no_async_mark && !cells_sync)) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
+    if (use_cells) { // the cells the beam ends can fall into: needs the pose boxes and the scan, not the map -- still in front of the join
         hipStream_t st = h->stream;
         if (!cells_sync) {
             // On a stream of their own.  The marking pass needs the pose boxes and the scan only, and claims nothing but table words that

@@ -1,6 +1,6 @@
 # per-launch durations of the scan-match kernel over the timed window, under the kernel trace, for an environment setting
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for e in "X=1" "PFSLAM_NO_ASYNC_MARK=1" "PFSLAM_CELLS_MODE=1"; do
+for e in "X=1" "PFSLAM_CELLS_MODE=1"; do
 rm -rf gpurun_out/pl; env $e timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pl -o kt -- python bench.py --no-cpu-baseline > /dev/null 2>&1
 python - "$e" <<'PY'
 import csv, glob, sys

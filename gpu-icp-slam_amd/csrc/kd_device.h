@@ -140,13 +140,9 @@ __device__ __forceinline__ void census_flush(const KdCensusLocal &c, KdCensus *o
 // LEAF: also report where the FIRST descent fell off the tree, as slot = node * 2 + (1 = right link, 0 = left link).  The
 // descent takes the left child exactly when query < node on the split axis, which is KDTree::InsertNode's rule
 // (kdtree.cpp:69-105), so that slot is where the query point would be inserted (the map update uses it, k_test_new).
-//
-// BOUNDED: nodes with an index >= `bound` do not exist for this traversal.  KDTree::InsertNode only ever hangs new nodes (the next free
-// indices) on null links of existing ones, so with bound = the size before a frame's insert this is the traversal of the tree as it
-// was -- whatever the insert, running beside it, has written by now (a link word is read old or new; new = an index >= bound).
-template <bool PLANAR, bool CENSUS = false, bool LEAF = false, bool BOUNDED = false>
+template <bool PLANAR, bool CENSUS = false, bool LEAF = false>
 __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, float pz, float sBest, int bestIdx, int head,
-                                         KdCensusLocal *census = nullptr, int *leaf_slot = nullptr, int bound = 0x7fffffff)
+                                         KdCensusLocal *census = nullptr, int *leaf_slot = nullptr)
 {
     int prevBest = -1;
     int leaf = -1;         // LEAF only
@@ -208,7 +204,6 @@ __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, fl
             if (!PLANAR) left = (t.planar && axis == 2) ? zleft : left;
             if (LEAF && leaf_open) leaf = head * 2 + ((lt && !(PLANAR && axis == 2)) ? 0 : 1);
             head = lt ? left : (int)nd.w;
-            if (BOUNDED) head = head >= bound ? -1 : head;
         }
         if (LEAF && leaf_open) {
             leaf_open = false;
@@ -246,7 +241,6 @@ __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, fl
         }
         if (!(hd < bestDist)) break;
         head = lt ? (int)nd.w : left; // the side the query is NOT on
-        if (BOUNDED) head = head >= bound ? -1 : head;
         if (CENSUS) {
             in_redesc = true;
             census->redesc++;

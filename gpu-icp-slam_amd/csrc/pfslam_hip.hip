@@ -231,16 +231,7 @@ struct pfslam_handle {
     bool mark_on_aux = false;
     hipStream_t istream = nullptr;  // the ICP solve: behind the previous frame's insert (ev_tree), beside its k_cells_update, in front of the scan-match kernel
     hipEvent_t ev_tree = nullptr;
-    // The map update in two chains (launch_map_update_device, PFSLAM_MAP_SPLIT=1): the walls -- direct list, traversal, insert, cell-row
-    // update -- stay on the aux stream, the frame's critical chain; the free cells -- rays into the masks, lists, traversal, weight
-    // passes, header -- run beside it on the ICP stream.  Bit-identical and 20 us shorter on the aux stream, but the frame does not get
-    // shorter while the particle chain on the main stream is as long as it is (tools/experiments/r04/README.md): off by default.
     void *pin_tree = nullptr;      // pinned staging of the map's device arrays (upload_tree)
-    hipStream_t fstream = nullptr; // = istream
-    hipEvent_t ev_pose = nullptr, ev_walls = nullptr, ev_free = nullptr;
-    bool map_split = false;
-    bool split_active = false; // part 1 of this frame's map update went out as two chains
-    bool free_event = false;   // ev_free is pending for the next ICP solve (it reads node weights)
     bool tree_event = false;
     hipStream_t cstream = nullptr;  // marking + walks of the new cells in the frame loops: beside the ICP solve, under the scan-match kernel
     hipEvent_t ev_walked = nullptr; // ... finished: the frame's insert (k_test_new changes the tree they read) waits for it
@@ -792,11 +783,6 @@ static int create_impl(pfslam_handle *h)
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
         HIPCHK(hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scored, hipEventDisableTiming));
-        h->fstream = h->istream; // (a fifth stream doubles the frame time on this runtime, measured; the ICP solve of the NEXT frame is what this stream carries otherwise)
-        HIPCHK(hipEventCreateWithFlags(&h->ev_pose, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_walls, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_free, hipEventDisableTiming));
-        h->map_split = getenv("PFSLAM_MAP_SPLIT") && atoi(getenv("PFSLAM_MAP_SPLIT")) != 0;
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -946,9 +932,6 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->istream) { (void)hipStreamSynchronize(h->istream); (void)hipStreamDestroy(h->istream); }
-    if (h->ev_pose) (void)hipEventDestroy(h->ev_pose);
-    if (h->ev_walls) (void)hipEventDestroy(h->ev_walls);
-    if (h->ev_free) (void)hipEventDestroy(h->ev_free);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
     if (h->ev_scored) (void)hipEventDestroy(h->ev_scored);
     if (h->ev_walked) (void)hipEventDestroy(h->ev_walked);

@@ -195,60 +195,3 @@ def test_cell_row_bookkeeping_is_deterministic(pkg):
         assert st["flags"] == 0 and st["walked_from_root"] == st["cells"] == st["claimed"] > 20000
         h.close()
     assert seen[0] == seen[1] == seen[2], seen
-
-
-def test_map_update_in_two_chains_replays_the_oracle(pkg, monkeypatch):
-    """PFSLAM_MAP_SPLIT=1 (read when a handle is created): the wall list by a direct sort (k_walls_direct), its traversal, the insert
-    and the cell-row update on the aux stream; rays, masks, free list, its traversal on the tree AS IT WAS (bounded, beside the insert),
-    the -1 and +4 weight passes and the header on the ICP stream.  Same frames, trees (weights included), particles and poses as the
-    oracle from an empty map through re-balances and resamples (every lag), 2000-beam scans (a 2048-key sort), and the same bytes and
-    cell-row bookkeeping as the one-chain update at 100 000 particles."""
-    assert pkg.device_count() > 0
-    monkeypatch.setenv("PFSLAM_MAP_SPLIT", "1")
-    for lag in (0, 2):
-        n, period = 640, 7
-        _, frames = pkg.synth.corridor_sequence(26, seed=9)
-        o = O.Slam(n, kd_capacity=1 << 16, balance_period=period)
-        h = pkg.PfSlam(n, kd_capacity=1 << 16, balance_period=period)
-        h.set_lag(lag)
-        for f, (_, scan) in enumerate(frames, start=1):
-            o.step(f, scan)
-            h.step(f, scan)
-            if f % 4 == 0 or f == len(frames):
-                assert h.trace() == o.trace(), (lag, f)
-                assert (bits(h.pose) == bits(o.pose)).all(), (lag, f)
-        assert h.map().tobytes() == o.tree().tobytes()
-        got, ref = h.particles(), o.particles()
-        for fld in ("x", "y", "theta", "w"):
-            assert (bits(got[fld]) == bits(ref[fld])).all(), (lag, fld)
-        h.close(); o.close()
-    nb = 2000
-    rng = np.random.RandomState(4)
-    o = O.Slam(96, n_beams=nb, kd_capacity=1 << 16)
-    h = pkg.PfSlam(96, n_beams=nb, kd_capacity=1 << 16)
-    for f in range(1, 8):
-        ang = np.deg2rad(-135.0 + 0.25 * np.arange(nb))
-        scan = (6.0 + 1.5 * np.cos(3.0 * ang + 0.05 * f) + rng.uniform(-0.01, 0.01, nb)).astype(np.float32)
-        o.step(f, scan); h.step(f, scan)
-        assert h.trace() == o.trace(), f
-    assert h.map().tobytes() == o.tree().tobytes()
-    h.close(); o.close()
-    # the bench workload, both ways
-    pts, segs = pkg.synth.make_map_points(100000, seed=1)
-    tree = pkg.kd_create(pts)
-    scans = [pkg.synth.make_scan(segs, (0.002 * i, 0.001 * i, 0.0004 * i), seed=2000 + i) for i in range(16)]
-    seen = []
-    for split in ("1", "0"):
-        monkeypatch.setenv("PFSLAM_MAP_SPLIT", split)
-        h = pkg.PfSlam(100000, kd_capacity=100000 + (1 << 18))
-        h.set_map(tree)
-        for f in range(1, 6):
-            h.motion_update(f)
-        for i, s in enumerate(scans):
-            h.step(6 + i, s)
-        st = h.cell_stats()
-        p = h.particles()
-        seen.append((h.map().tobytes(), tuple(h.pose.view(np.int32)), p["w"].tobytes(), p["x"].tobytes(), st["cells"], st["rows"], st["extended"], h.trace()))
-        assert st["flags"] == 0 and st["rows"] > 0
-        h.close()
-    assert seen[0] == seen[1]

@@ -393,17 +393,20 @@ extern "C" int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out)
     std::vector<Pt> buf(n);
     TiedPerms tied(n);
     // PFSLAM_PLAIN_SORT, or a NaN coordinate (no strict weak order: what std::sort does then is its own business): no shortcut of any kind
-    std::atomic<int> nan{plain_sort_forced() ? 1 : 0};
+    std::atomic<int> nan{plain_sort_forced() ? 1 : 0}, zdiff{0};
+    const float z0 = pts_xyzw[2];
     {   // copy + NaN scan, in slices on the threads the sorts will use (16 MB of traffic at 500 k points: 1 ms on one)
         const int T = n >= (1 << 17) ? std::min(sort_thread_budget(), 8) : 1;
         auto slice = [&](int t) {
             const int lo = (int)((long long)n * t / T), hi = (int)((long long)n * (t + 1) / T);
-            bool bad = false;
+            bool bad = false, zd = false;
             for (int i = lo; i < hi; i++) {
                 buf[i] = Pt{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
                 bad |= buf[i].x != buf[i].x || buf[i].y != buf[i].y || buf[i].z != buf[i].z;
+                zd |= buf[i].z != z0;
             }
             if (bad) nan = 1;
+            if (zd) zdiff = 1;
         };
         std::vector<std::thread> ts;
         for (int t = 1; t < T; t++) {
@@ -413,6 +416,19 @@ extern "C" int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out)
         for (auto &t : ts) t.join();
     }
     const bool plain = nan.load() != 0;
+    // The permutations of the upper z levels of a planar map depend on n only: a thread of its own has them ready by the time the build
+    // gets there (depth 2 at 500 k points: a 125 k-index sort, ~1 ms that four sub-builds would otherwise wait for)
+    std::thread ahead;
+    if (!plain && !zdiff.load() && n >= (1 << 16) && sort_thread_budget() > 2) {
+        try {
+            ahead = std::thread([&] {
+                for (int d = 2; d <= 8; d += 3)
+                    for (int e = 0; e < 2; e++)
+                        if ((size_t)(2 * d + e) < tied.entries.size()) tied.get(d, tied.entries[2 * d + e]->len);
+            });
+        } catch (const std::system_error &) {}
+    }
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ahead};
     level_sort(buf.data(), n, [](const Pt &p) { return p.x; }, plain ? nullptr : &tied, -1); // KDTree::Create pre-sorts on x before the recursive sort
     const unsigned hw = (unsigned)sort_thread_budget(); // usable cores, shared with the node's other ranks
     // up to 16 concurrent sub-builds, 32 for a big map (500 k points on the 16 cores of the GPU box: 29 -> 25 ms; no gain at 100 k)

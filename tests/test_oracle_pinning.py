@@ -268,3 +268,47 @@ def test_parallel_host_sort_is_std_sort_on_tied_keys(pkg):
             assert out == tree.tobytes(), env
     finally:
         os.remove(path)
+
+
+def test_restated_host_sort_equals_std_sort_on_many_shapes(pkg):
+    """The restated introsort of csrc/kd_host.cpp (branch-free partition with its exact meeting-point rule, rank sort of the <= 16-element
+    pieces, tied ranges by a cached permutation) against the library call (PFSLAM_PLAIN_SORT=1 in a child process): trees of point sets
+    whose levels exercise the partition's tail (sizes around 2 x 64), sorted / reversed / organ-pipe / few-valued / all-equal keys,
+    -0.0 beside +0.0, denormals, and a NaN coordinate (which must send the whole build to the library call)."""
+    import subprocess, sys, os
+    rng = np.random.RandomState(77)
+    cases = []
+    for n in (1, 2, 16, 17, 18, 33, 63, 64, 65, 127, 128, 129, 130, 131, 200, 257, 300, 401, 1000, 2049, 5000, 33000):
+        for kind in range(7):
+            p = np.zeros((n, 4), np.float32)
+            i = np.arange(n)
+            if kind == 0:
+                p[:, 0] = rng.randint(-50, 50, n) * np.float32(0.05); p[:, 1] = rng.randint(-50, 50, n) * np.float32(0.05)
+            elif kind == 1:
+                p[:, 0] = i * np.float32(0.05); p[:, 1] = (n - i) * np.float32(0.05)                 # sorted / reversed
+            elif kind == 2:
+                p[:, 0] = np.minimum(i, n - i) * np.float32(0.05); p[:, 1] = (i % 3) * np.float32(0.05)  # organ pipe / three values
+            elif kind == 3:
+                p[:, 0] = np.float32(1.25); p[:, 1] = rng.randint(0, 2, n) * np.float32(0.05)       # one wall
+            elif kind == 4:
+                p[:, 0] = rng.uniform(-3, 3, n); p[:, 1] = rng.uniform(-3, 3, n); p[:, 2] = rng.randint(0, 3, n)  # untied, 3-D
+            elif kind == 5:
+                p[:, 0] = np.where(rng.randint(0, 2, n) == 0, np.float32(0.0), np.float32(-0.0)); p[:, 1] = rng.randint(0, 4, n) * np.float32(1e-41)
+            else:
+                p[:, 0] = rng.randint(-5, 5, n); p[:, 1] = rng.randint(-5, 5, n)
+                if n > 2: p[n // 2, 1] = np.nan
+            p[:, 3] = i
+            cases.append(p)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pf_sortshapes_%d.npz" % os.getpid())
+    np.savez(path, *cases)
+    code = ("import importlib, numpy as np, sys, hashlib; pkg = importlib.import_module('gpu-icp-slam_amd'); z = np.load(sys.argv[1]); "
+            "print(' '.join(hashlib.md5(pkg.kd_create(z['arr_%d' % k]).tobytes()).hexdigest() for k in range(len(z.files))))")
+    try:
+        out = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, PFSLAM_PLAIN_SORT="1"),
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, check=True, text=True).stdout.split()
+    finally:
+        os.remove(path)
+    import hashlib
+    assert len(out) == len(cases)
+    for k, p in enumerate(cases):
+        assert hashlib.md5(pkg.kd_create(p).tobytes()).hexdigest() == out[k], (k, len(p), k % 7)

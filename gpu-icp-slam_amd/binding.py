@@ -25,6 +25,7 @@ SYMBOLS = [
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
     "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads",
+    "pfslam_set_serial", "pfslam_debug_check_cells", "pfslam_set_probe", "pfslam_get_probe", "pfslam_probe_name",
     "pfslam_time_score_grid", "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
 ]
 
@@ -135,6 +136,12 @@ def load():
     L.pfslam_ubench_gather.argtypes = [vp, vp]
     L.pfslam_plan_stats.argtypes = [vp, vp]
     L.pfslam_cell_stats.argtypes = [vp, vp]
+    L.pfslam_set_serial.argtypes = [vp, i32]
+    L.pfslam_debug_check_cells.argtypes = [vp, vp]
+    L.pfslam_set_probe.argtypes = [vp, i32]
+    L.pfslam_get_probe.argtypes = [vp, vp, i32, vp, vp]
+    L.pfslam_probe_name.argtypes = [i32]
+    L.pfslam_probe_name.restype = C.c_char_p
     L.pfslam_score_grid.argtypes = [vp, vp]
     L.pfslam_update_map_grid.argtypes = [vp]
     L.pfslam_traverse.argtypes = [vp, vp, i32, vp]
@@ -403,6 +410,37 @@ class PfSlam:
         keys = ("cells", "rows", "candidates", "redescent_candidates", "cells_without_row", "pool_slots", "window_kx", "window_ky",
                 "walked_from_root", "extended", "reused", "claimed", "flags", "updates", "wipes", "suspended")
         return dict(zip(keys, [float(v) for v in out]))
+
+    def set_serial(self, on):
+        _chk(self.L.pfslam_set_serial(self._h, int(on)), "pfslam_set_serial")
+
+    def check_cells(self):
+        """Invariants of the persistent cell rows, checked on the device (include/pfslam.h): counts + violations (must be zero)."""
+        out = (C.c_longlong * 16)()
+        _chk(self.L.pfslam_debug_check_cells(self._h, out), "pfslam_debug_check_cells")
+        keys = ("records", "unwalked", "fresh", "published", "row_words", "pending_words", "fallback_words", "dead",
+                "v_unwalked_not_pending", "v_unpublished_word", "v_row_outside_alloc", "v_row_not_candidate", "v_watched_link_has_child",
+                "v_bad_link", "v_dead_has_row", "v_counters")
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["violations"] = sum(v for k, v in d.items() if k.startswith("v_"))
+        return d
+
+    def set_probe(self, frames):
+        _chk(self.L.pfslam_set_probe(self._h, int(frames)), "pfslam_set_probe")
+
+    def probe(self, frames=4096):
+        """Wall-clock stamps (microseconds, relative to the first stamp) of the launches of the last round-5 frames: (names, array[f][slot])."""
+        buf = np.zeros((frames, 32), np.uint64)
+        n, last = C.c_int(0), C.c_int(0)
+        _chk(self.L.pfslam_get_probe(self._h, _p(buf), frames, C.byref(n), C.byref(last)), "pfslam_get_probe")
+        names = []
+        for k in range(32):
+            s = self.L.pfslam_probe_name(k).decode()
+            if not s:
+                break
+            names.append(s)
+        t = buf[:n.value, :len(names)].astype(np.float64) * 0.01
+        return names, t, last.value
 
     def ubench_gather(self):
         out = (C.c_double * 4)()

@@ -140,9 +140,15 @@ __device__ __forceinline__ void census_flush(const KdCensusLocal &c, KdCensus *o
 // LEAF: also report where the FIRST descent fell off the tree, as slot = node * 2 + (1 = right link, 0 = left link).  The
 // descent takes the left child exactly when query < node on the split axis, which is KDTree::InsertNode's rule
 // (kdtree.cpp:69-105), so that slot is where the query point would be inserted (the map update uses it, k_test_new).
-template <bool PLANAR, bool CENSUS = false, bool LEAF = false>
+//
+// BOUNDED (round 5): the traversal of the tree AS IT WAS when it had `bound` nodes.  Between two re-balances the tree is append-only
+// (KDTree::InsertNode, kdtree.cpp:69-105): an insert writes nodes with indices >= the old size and hangs each on a link that was
+// empty, so "ignore every child index >= bound" IS the old tree -- whatever the insert that runs beside this traversal has or has
+// not written yet (a 16-byte record is read in one piece; a link is either still empty or names a node >= bound).  The frame's
+// free-cell pass of kernUpdateMapKD (kernel.cu:1468-1483 runs before the insert of kernel.cu:1512-1517) uses it on a stream of its own.
+template <bool PLANAR, bool CENSUS = false, bool LEAF = false, bool BOUNDED = false>
 __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, float pz, float sBest, int bestIdx, int head,
-                                         KdCensusLocal *census = nullptr, int *leaf_slot = nullptr)
+                                         KdCensusLocal *census = nullptr, int *leaf_slot = nullptr, int bound = 0x7fffffff)
 {
     int prevBest = -1;
     int leaf = -1;         // LEAF only
@@ -204,6 +210,7 @@ __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, fl
             if (!PLANAR) left = (t.planar && axis == 2) ? zleft : left;
             if (LEAF && leaf_open) leaf = head * 2 + ((lt && !(PLANAR && axis == 2)) ? 0 : 1);
             head = lt ? left : (int)nd.w;
+            if (BOUNDED && head >= bound) head = -1;
         }
         if (LEAF && leaf_open) {
             leaf_open = false;
@@ -241,6 +248,7 @@ __device__ __forceinline__ int kd_resume(const KdView &t, float px, float py, fl
         }
         if (!(hd < bestDist)) break;
         head = lt ? (int)nd.w : left; // the side the query is NOT on
+        if (BOUNDED && head >= bound) head = -1;
         if (CENSUS) {
             in_redesc = true;
             census->redesc++;

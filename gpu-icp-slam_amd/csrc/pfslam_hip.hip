@@ -71,7 +71,9 @@ struct HostHeader {
     int32_t seq; // ticket of the frame that wrote this slot
     float cloud_sigma; // spread of the particle cloud as the frame's lane order saw it (m; max of x, y, reach x heading)
     float theta_max;   // largest |heading| among the frame's particles (inf: a NaN among them); 0 when the pass made no pose boxes
-    int32_t pad[13];
+    int32_t seq2;      // round-5 frame loop: ticket of the frame whose PARTICLE chain wrote r, r2, neff, stats, cloud_sigma, theta_max
+                       // (`seq` then covers the map update's fields only; the host waits for both)
+    int32_t pad[12];
 };
 static_assert(sizeof(HostHeader) == 128, "HostHeader is two 64-byte lines");
 #define PF_HDR_SLOTS 4 /* header / scan staging slots: frames in flight + 1 (PF_MAX_LAG + 2) */
@@ -152,7 +154,7 @@ struct pfslam_handle {
     // device, there is no idle gap between frames.  Any other entry point settles the frames in flight first (settle()).
     HostHeader *h_hdr = nullptr, *hdr_dev = nullptr; // PF_HDR_SLOTS pinned headers and their device view
     float *h_scan = nullptr;                         // PF_HDR_SLOTS pinned scan staging buffers
-    struct Frame { int seq, frame, kind; bool boxes = false; }; // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once); boxes: its scoring pass made pose boxes (theta_max of its header is this frame's)
+    struct Frame { int seq, frame, kind; bool boxes = false; bool v2 = false; }; // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once); boxes: its scoring pass made pose boxes (theta_max of its header is this frame's)
     std::deque<Frame> in_flight;
     int seq = 0; // tickets handed out
     int cur_seq = 0, cur_frame = 0; // the frame being enqueued (frame_front .. frame_tail)
@@ -239,7 +241,39 @@ struct pfslam_handle {
     bool cells_snap = false;       // this frame's k_cells_update<true> may run beside the next frame's marking pass: records below the walk pass's snapshot only
     pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
+    // ---- round-5 frame loop (pfslam_frame.hip.inc): four in-order chains, a fixed set of events between them ----
+    int serial = 0;               // PFSLAM_SERIAL=1: every frame's launches on ONE stream, in enqueue order (same results, same bookkeeping)
+    int frame_v2 = 1;             // PFSLAM_FRAME_V2=0: the round-4 frame (A/B runs)
+    bool pipe_live = false;       // the last frame was a round-5 frame: its events and ring slots are what the next one waits on
+    bool cloud_valid = false;     // the cloud statistics k_motion_count starts from describe the current particles
+    int publish_lag = 1;          // a publishing pass takes the records walked `publish_lag` frames ago (ordered through ev_join)
+    int *fs = nullptr;            // frame state words (PF_FS_*)
+    int *wcounts = nullptr;       // k_walls: wall cells, new walls, header flags, map size
+    int *wall_c2 = nullptr;       // nearest index of every wall of the frame (k_walls -> k_wall_weights)
+    long long *fstats = nullptr;  // packed min / max keys, [2][4] by ticket parity (a frame's last reduce workgroup resets the other one)
+    float *cloud = nullptr;       // cloud statistics {mean x, y, heading, spread}, [2][4] by ticket parity
+    float *sigr = nullptr;        // [PF_FRAME_RING][80]: {spread, -, 64 partial maxima of |heading|} of a frame's cloud -> header part A
+    int *order_ring = nullptr;    // [PF_FRAME_RING][n]: lane order by ticket (the cells' stream reads a frame's order while the next is made)
+    short *pgroup = nullptr;      // group-major 16-bit beam-chunk partials
+    size_t pgroup_elems = 0;
+    hipStream_t fstream = nullptr; // F: the free cells' chain (the round-4 ICP stream's place: a FIFTH stream halves the frame rate on this runtime)
+    hipEvent_t ev_go = nullptr, ev_reduced = nullptr, ev_tree2 = nullptr, ev_order = nullptr, ev_icp = nullptr, ev_ftail = nullptr, ev_shift = nullptr;
+    hipEvent_t ev_marked_r[4] = {nullptr, nullptr, nullptr, nullptr}, ev_walked_r[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr}; // settle(): the tails of C, F, K -> P
+    bool shift_pending = false;   // an odometry shift was enqueued behind the last frame: the next ICP solve waits for it
+    bool balance_done = false;    // pfslam_step has already re-balanced for the frame frame_front is about to enqueue
+    bool walls_attr_set = false;
+    // frame probe (pfslam_set_probe): wall-clock stamps by the first thread of a frame's launches
+    unsigned long long *probe = nullptr;
+    int probe_frames = 0;
 };
+#define PF_PROBE_SLOTS 32
+enum { PB_ICP = 0, PB_MOTION, PB_SCATTER, PB_BOX, PB_MARK, PB_WALK, PB_SCORE, PB_REDUCE, PB_WALLS, PB_UPDATE, PB_WEIGHTS, PB_APPLY, PB_GATHER, PB_RAYS, PB_COUNT,
+       PB_LISTS, PB_FREE, PB_WALLW, PB_REDUCE_LAST, PB_WALLS_KEYS, PB_WALLS_SORTED, PB_WALLS_TRAV, PB_WALLS_END, PB_ICP_SOLVE, PB_ICP_END, PB_END };
+static const char *const pb_names[PB_END] = {"K icp", "P motion+cells", "P scatter", "K boxes", "K mark", "K walk", "C scan-match", "C reduce", "C walls+insert",
+                                             "C cells update", "P weights", "P scan apply", "P sample+gather", "F rays", "F count", "F lists", "F free pass", "F wall weights",
+                                             "C reduce: last wg", "C walls: keys", "C walls: sorted", "C walls: traversed", "C walls: end", "K icp: solve", "K icp: end"};
+static_assert(PB_END <= PF_PROBE_SLOTS, "probe slots");
 
 // ==========================================================================================
 // kernels
@@ -750,6 +784,8 @@ static int dalloc(T **p, size_t count)
 
 static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw, h->planar}; }
 static int settle(pfslam_handle *h);   // finish and book the frames in flight (pfslam_stages.hip.inc)
+static int join_all(pfslam_handle *h); // round-5 frames: the tails of the chain / free-cell / cell streams -> the handle's stream
+static void frame_free(pfslam_handle *h);
 static int join_map(pfslam_handle *h); // main stream waits for the map update a frame left on the aux stream
 
 extern "C" int pfslam_destroy(pfslam_handle *h);
@@ -783,6 +819,10 @@ static int create_impl(pfslam_handle *h)
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
         HIPCHK(hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scored, hipEventDisableTiming));
+        h->fstream = h->istream; // round-5 frames: the free cells' chain (their ICP solve rides on the cells' stream)
+        if (const char *e = getenv("PFSLAM_SERIAL")) h->serial = atoi(e) != 0;
+        if (const char *e = getenv("PFSLAM_FRAME_V2")) h->frame_v2 = atoi(e) != 0;
+        if (const char *e = getenv("PFSLAM_PUBLISH_LAG")) h->publish_lag = std::min(std::max(atoi(e), 1), 2);
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -958,6 +998,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     if (h->ev_marked) (void)hipEventDestroy(h->ev_marked);
     if (h->beam_angle) (void)hipFree(h->beam_angle);
     if (h->fit_acc) (void)hipFree(h->fit_acc);
+    frame_free(h);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1188,6 +1229,7 @@ static int upload_tree(pfslam_handle *h, const pfslam_node *nodes, int n, std::v
     h->w_absmax = wabs;
     h->lattice_ok = lattice;
     h->cells_wipe_pending = true; // rows of the previous map
+    h->pipe_live = false;         // (round-5 frames: the tree-size words of the frame ring start over)
     h->cells_suspended = false;
     h->cells_full_frame = -1;
     return 0;
@@ -1225,6 +1267,7 @@ extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, 
         for (int i = 0; i < n; i++) tb = p[i].theta == p[i].theta ? std::max(tb, fabsf(p[i].theta)) : INFINITY;
         h->theta_bound = tb;
         h->theta_shift = 0.0f;
+        h->cloud_valid = false; // (round-5 frames: k_motion_count's statistics describe the cloud this call replaces)
     }
     HIPCHK(hipMemcpyAsync(h->x, &tmp[0], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->y, &tmp[n], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -1382,10 +1425,13 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
 
 // ---- odometry hook (no reference counterpart: the reference's filter has no motion model besides the diffusion) -------------
 __global__ __launch_bounds__(256) void k_shift(float *__restrict__ x, float *__restrict__ y, float *__restrict__ th, int n, float dx, float dy,
-                                               float dt, float *__restrict__ pose)
+                                               float dt, float *__restrict__ pose, float *__restrict__ cloud)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { pose[0] = pose[0] + dx; pose[1] = pose[1] + dy; pose[2] = pose[2] + dt; }
+    if (i < 2 && cloud) { // round-5 frames: the cloud statistics of both ticket parities move along (performance only)
+        cloud[4 * i] += dx; cloud[4 * i + 1] += dy; cloud[4 * i + 2] += dt;
+    }
     if (i >= n) return;
     x[i] = x[i] + dx;
     y[i] = y[i] + dy;
@@ -1398,10 +1444,21 @@ extern "C" int pfslam_shift_particles(pfslam_handle *h, const float delta[3])
     if (!h || !delta) return fail("pfslam_shift_particles: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(join_map(h)); // the map update a frame left on the aux stream reads the pose
-    h->theta_shift = delta[2] == delta[2] ? h->theta_shift + fabsf(delta[2]) : INFINITY; // (headers of frames enqueued before this do not know of it)
+    if (h->pipe_live && !h->serial) { // round-5 frames: the pose's readers of the last frame are k_walls (chain) and the free-cell chain
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tree2, 0));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ftail, 0));
+    }
+    const float ad = delta[2] == delta[2] ? fabsf(delta[2]) : INFINITY;
+    h->theta_shift += ad; // (headers of frames enqueued before this do not know of it)
+    h->theta_bound += ad; // ... and the choice of the scan-match kernel's instantiation must: the bound itself moves at once
     h->theta_shift_seq = h->seq;
-    hipLaunchKernelGGL(k_shift, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, delta[0], delta[1], delta[2], h->pose);
+    hipLaunchKernelGGL(k_shift, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, delta[0], delta[1], delta[2], h->pose,
+                       h->cloud_valid ? h->cloud : (float *)nullptr);
     HIPCHK(hipGetLastError());
+    if (h->pipe_live) {
+        HIPCHK(hipEventRecord(h->ev_shift, h->stream));
+        h->shift_pending = true;
+    }
     return 0;
 }
 
@@ -1471,6 +1528,24 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
     return 0;
 }
 
+// How a scoring pass is organised (launch_score and the round-5 frame agree through this): lattice-cell rows, the round-2 plan, or the plain traversal
+static int plan_min_particles()
+{
+    static const int v = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 4608;
+    return v;
+}
+static bool org_use_cells(const pfslam_handle *h, bool *use_plan)
+{
+    const int plan_min_n = plan_min_particles();
+    const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
+    const float Dside = h->n <= 400000 ? 64.0f : 128.0f;
+    const float box_cells = 2.0f * (6.4f * h->cloud_sigma / Dside) * cbrtf(64.0f * Dside * Dside * Dside / (float)h->n) / std::min(h->cfg.map_res_x, h->cfg.map_res_y);
+    static const float box_max = getenv("PFSLAM_CELLS_BOX_MAX") ? (float)atof(getenv("PFSLAM_CELLS_BOX_MAX")) : 24.0f;
+    const bool narrow = h->variant == 3 || !(box_cells > box_max);
+    const bool use_cells = organised && h->lattice_ok && h->variant != 4 && !h->cells_suspended && narrow; // lattice-cell rows (kd_cells.hip.inc)
+    if (use_plan) *use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);
+    return use_cells;
+}
 struct ShardPack;
 __global__ void k_reduce_partials_minmax(float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
                                          const float *x, const float *y, const float *th, ShardPack *pack, int wipe, int p16);
@@ -1506,18 +1581,13 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // With few particles neither pays for its extra launches (~0.1 ms of marking + rows): measured scoring pass at 3 k / 5 k / 10 k /
     // 50 k particles: cell rows 0.175 / 0.185 / 0.251 / 0.502 ms, plan 0.162 / 0.204 / 0.312 / 0.825 ms, plain traversal 0.139 / 0.198 /
     // 0.351 / 1.307 ms (tools/experiments/r03/cells_threshold.py): organised from ~4.6 k particles on.
-    static const int plan_min_n = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 4608;
-    const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
+    bool use_plan_ = false;
+    const bool use_cells_ = org_use_cells(h, &use_plan_);
     // The marking pass of the cell rows costs the area of a wave's beam-end box in lattice cells: a wave's 64 Hilbert neighbours span
     // ~(64 D^3 / N)^(1/3) of the D^3 cells laid over +-3.2 sigma, in position and (x reach) in heading.  Up to ~24 cells per side the
     // rows win (0.5 m of spread at 100 k particles and 2.5 cm: cell rows 0.48 / 0.84 / 1.9 ms at sigma 0.05 / 0.2 / 0.5 m against 1.2 / 1.9 / 2.4 ms
     // for the plan); at 1 m they took 60 ms against 2.7 (tools/sigma_sweep.py, profiles/r04_sigma_sweep.json).  variant 3 forces them.
-    const float Dside = h->n <= 400000 ? 64.0f : 128.0f;
-    const float box_cells = 2.0f * (6.4f * h->cloud_sigma / Dside) * cbrtf(64.0f * Dside * Dside * Dside / (float)h->n) / std::min(h->cfg.map_res_x, h->cfg.map_res_y);
-    static const float box_max = getenv("PFSLAM_CELLS_BOX_MAX") ? (float)atof(getenv("PFSLAM_CELLS_BOX_MAX")) : 24.0f;
-    const bool narrow = h->variant == 3 || !(box_cells > box_max);
-    const bool use_cells = organised && h->lattice_ok && h->variant != 4 && !h->cells_suspended && narrow; // lattice-cell rows (kd_cells.hip.inc)
-    const bool use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);
+    const bool use_cells = use_cells_, use_plan = use_plan_; // (org_use_cells: lattice-cell rows, else the round-2 plan, else the plain traversal)
     const CellGeom geo{h->cfg.map_res_x, h->cfg.map_res_y, 1.0f / h->cfg.map_res_x, 1.0f / h->cfg.map_res_y};
     if (use_cells && !h->cell_tab) {
         CHK(dalloc(&h->cell_tab, (size_t)PF_CELL_WIN * PF_CELL_WIN));
@@ -1930,6 +2000,149 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
     return 0;
 }
 
+// ---- the cell rows' invariants, checked on the device (tests; PFSLAM_CHECK_CELLS=1 makes pfslam_synchronize run it) -------------------
+// An oracle comparison sees wrong SCORES; it cannot see rows that are right today and that nobody watches (stale at the next insert
+// there), records read half-written, or a table word nobody accounts for -- the round-4 races were of that kind.  What must hold
+// whenever no frame is in flight:
+//   * a record of the current generation that is published (neither FRESH nor DEAD) owns its four table words: each is FALLBACK or a row
+//     whose slots lie inside the record's pool allocation and list, in order, nodes the record holds as candidates;
+//   * none of its watched links -- the first descent's, every candidate's re-descent walk's -- has a child in the tree (a link that
+//     gained a node and was not extended is a stale row waiting to happen);
+//   * a claimed cell that is not published yet (never walked, or walked and FRESH) still has its claim word PENDING;
+//   * the table holds exactly the rows / fallback words the counters say, and one PENDING word per unpublished record.
+// out: [0] records  [1] never walked  [2] fresh  [3] published  [4] row words in the table  [5] pending words  [6] fallback words
+//      [7] dead records  [8..15] violations: unwalked-not-pending, fresh-not-pending, row outside its allocation, row slot not a candidate
+//      (or out of order), watched link has a child, malformed link word, dead record with a row, counter mismatch (host side)
+__global__ __launch_bounds__(256) void k_cells_check(pf::KdView tree, const unsigned *__restrict__ tab, const int *__restrict__ list, const int *__restrict__ cs,
+                                                     const uint4 *__restrict__ pool, const int *__restrict__ rec_base, int gen, unsigned long long *__restrict__ out)
+{
+    const int count = min(cs[PF_CS_COUNT], cs[PF_CS_LIST_CAP]);
+    unsigned long long c[16] = {0};
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < count; r += gridDim.x * 256) {
+        const int *rec = rec_base + (size_t)r * PF_REC_WORDS;
+        const int cell = list[r];
+        c[0]++;
+        const unsigned w0 = tab[cell];
+        if (rec[3] != gen) { c[1]++; if (w0 != PF_CELL_PENDING) c[8]++; continue; }
+        const int m = rec[2] & 0xff, fl = rec[2] >> 16;
+        if (fl & PF_RF_FRESH) { c[2]++; if (w0 != PF_CELL_PENDING) c[9]++; continue; }
+        const unsigned wd[4] = {w0, tab[cell + 1], tab[cell + PF_CELL_WIN], tab[cell + PF_CELL_WIN + 1]};
+        if (fl & PF_RF_DEAD) {
+            c[7]++;
+            for (int b = 0; b < 4; b++) if (wd[b] != PF_CELL_FALLBACK) c[14]++;
+            continue;
+        }
+        c[3]++;
+        const int p0 = rec[PF_REC_POOL], plen = rec[PF_REC_POOL + 1];
+        for (int b = 0; b < 4; b++) {
+            if (wd[b] == PF_CELL_FALLBACK) continue;
+            if (wd[b] == 0u || wd[b] >= 0x40000000u) { c[9]++; continue; }
+            const int n1 = (int)(wd[b] & 15u), n2 = (int)((wd[b] >> 4) & 15u), off = (int)(wd[b] >> 8);
+            if (off < p0 || off + n1 + (n2 == 15 ? 0 : n2) > p0 + plen || n1 < 1) { c[10]++; continue; }
+            int pos = 0;
+            for (int k = 0; k < n1; k++) { // the row's candidates are a sub-sequence of the record's
+                const int node = (int)(pool[off + k].z & 0x3fffffffu);
+                while (pos < m && rec[PF_REC_CAND + pos] != node) pos++;
+                if (pos == m) { c[11]++; break; }
+                pos++;
+            }
+        }
+        if (rec[1] < 0 || watched_child(tree, rec[1]) >= 0) c[12]++;
+        if (!(fl & PF_RF_ROVER))
+            for (int k = 0; k < m; k++) {
+                const int ct = rec[PF_REC_TERM + k];
+                if (ct < -1) c[13]++;
+                else if (ct >= 0 && watched_child(tree, ct) >= 0) c[12]++;
+            }
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)PF_CELL_WIN * PF_CELL_WIN; i += (size_t)gridDim.x * 256) {
+        const unsigned w = tab[i];
+        if (w == 0u) continue;
+        if (w == PF_CELL_PENDING) c[5]++;
+        else if (w == PF_CELL_FALLBACK) c[6]++;
+        else c[4]++;
+    }
+    for (int k = 0; k < 15; k++) {
+        unsigned long long v = c[k];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[k], v);
+    }
+}
+extern "C" int pfslam_debug_check_cells(pfslam_handle *h, long long out[16])
+{
+    if (!h || !out) return fail("pfslam_debug_check_cells: bad argument");
+    for (int k = 0; k < 16; k++) out[k] = 0;
+    if (!h->cell_tab || !h->cells_valid || h->cells_wipe_pending) return 0;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    unsigned long long *d = nullptr;
+    CHK(dalloc(&d, 16));
+    HIPCHK(hipMemsetAsync(d, 0, 128, h->stream));
+    hipLaunchKernelGGL(k_cells_check, dim3(2048), dim3(256), 0, h->stream, kd_view(h), (const unsigned *)h->cell_tab, (const int *)h->cell_list,
+                       (const int *)h->cell_state, (const uint4 *)h->cell_pool, (const int *)h->cell_rec, h->cells_gen, d);
+    HIPCHK(hipGetLastError());
+    int cs[PF_CS_WORDS];
+    HIPCHK(hipMemcpyAsync(out, d, 128, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cs, h->cell_state, sizeof(cs), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d));
+    // the counters against the table itself (exact while neither the list nor the pool has overflowed)
+    if (!(cs[PF_CS_FLAGS] & (PF_CF_LIST_FULL | PF_CF_POOL_FULL)))
+        out[15] = (out[4] != cs[PF_CS_ROWS]) + (out[6] != cs[PF_CS_NONE]) + (out[5] != out[1] + out[2]);
+    return 0;
+}
+
+// ---- frame probe: where a round-5 frame's time goes, from the frame's own kernels ---------------------------------------------------
+// frames > 0: keep the stamps of the last `frames` tickets (the first thread of each launch of a round-5 frame stores the 100 MHz wall
+// clock); 0: off.  pfslam_get_probe copies them out: out[f][PF_PROBE_SLOTS] for tickets last - n + 1 .. last (0 = launch did not run).
+extern "C" int pfslam_set_probe(pfslam_handle *h, int frames)
+{
+    if (!h || frames < 0 || frames > 4096) return fail("pfslam_set_probe: 0 .. 4096 frames");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->probe) HIPCHK(hipFree(h->probe));
+    h->probe = nullptr;
+    h->probe_frames = 0;
+    if (frames > 0) {
+        CHK(dalloc(&h->probe, (size_t)frames * PF_PROBE_SLOTS));
+        HIPCHK(hipMemset(h->probe, 0, (size_t)frames * PF_PROBE_SLOTS * 8));
+        h->probe_frames = frames;
+    }
+    return 0;
+}
+extern "C" int pfslam_get_probe(pfslam_handle *h, unsigned long long *out, int cap_frames, int *n_frames, int *last_ticket)
+{
+    if (!h || !n_frames || (cap_frames > 0 && !out)) return fail("pfslam_get_probe: bad argument");
+    *n_frames = 0;
+    if (last_ticket) *last_ticket = h->seq;
+    if (!h->probe) return 0;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int n = std::min(std::min(cap_frames, h->probe_frames), h->seq);
+    std::vector<unsigned long long> all((size_t)h->probe_frames * PF_PROBE_SLOTS);
+    HIPCHK(hipMemcpy(all.data(), h->probe, all.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; k++) {
+        const int ticket = h->seq - n + 1 + k;
+        memcpy(out + (size_t)k * PF_PROBE_SLOTS, &all[(size_t)(ticket % h->probe_frames) * PF_PROBE_SLOTS], PF_PROBE_SLOTS * 8);
+    }
+    *n_frames = n;
+    return 0;
+}
+extern "C" const char *pfslam_probe_name(int slot) { return slot >= 0 && slot < PB_END ? pb_names[slot] : ""; }
+// 1: every frame's launches on one stream, in enqueue order (what PFSLAM_SERIAL=1 sets at creation); same results, same bookkeeping
+extern "C" int pfslam_set_serial(pfslam_handle *h, int serial)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->serial = serial != 0;
+    h->pipe_live = false;
+    return 0;
+}
+
 // ---- measurement support: the chip's wave-gather rate, measured live (the roofline the score kernel is priced against) ----
 // Dependent-free wave-level 16-byte gathers from a 2 MB table (cache resident, like the hot map records), 8 waves per SIMD, 8
 // gathers in flight per lane; every lane of a wave reads the same pseudo-random record (the cheapest case for the L1: what is
@@ -2075,4 +2288,7 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
     return 0;
 }
 
+static bool frame_v2_ok(pfslam_handle *h, int *chunks_out, int *bpc_out);                  // pfslam_frame.hip.inc
+static int frame_v2(pfslam_handle *h, int frame, const float *scan_host, int used, int bpc); // (the round-5 frame of pfslam_step)
 #include "pfslam_stages.hip.inc"
+#include "pfslam_frame.hip.inc"

@@ -294,6 +294,23 @@ int pfslam_cell_stats(pfslam_handle *h, double out[16]);
  * weights) over `iters` launches each, HIP events on the handle's stream */
 int pfslam_time_score_grid(pfslam_handle *h, int iters, float *ms_kernel, float *ms_pass);
 int pfslam_set_variant(pfslam_handle *h, int variant);
+/* ---- round-5 frame loop: test and measurement support (no reference counterpart) ----
+ * pfslam_set_serial(h, 1): every launch of every frame on ONE stream, in the order the four chains of a frame are enqueued (what the
+ * environment variable PFSLAM_SERIAL=1 sets at creation).  Results and the cell rows' bookkeeping are the same as with the chains on their
+ * own streams; tests/test_gpu_frame.py steps the same cases both ways and compares.
+ * pfslam_debug_check_cells: the invariants of the persistent cell rows checked on the device, with no frame in flight -- out[0] records,
+ * [1] never walked, [2] walked and not yet published, [3] published, [4] row words in the table, [5] pending words, [6] fallback words,
+ * [7] records without rows; VIOLATIONS (all zero or the bookkeeping is broken): [8] claimed cell neither walked nor pending, [9] unpublished
+ * record whose claim word is not pending (or a malformed word), [10] row outside its record's pool allocation, [11] row slot that is not a
+ * candidate of its record (or out of order), [12] a watched link that has gained a node and was not extended (a stale row waiting to
+ * happen), [13] malformed link word, [14] record without rows that has one, [15] the table does not hold what the counters say.
+ * pfslam_set_probe(h, frames) / pfslam_get_probe: the first thread of every launch of a round-5 frame stores the 100 MHz wall clock;
+ * out[f][32] for the last n tickets (0 = that launch did not run), slot names from pfslam_probe_name. */
+int pfslam_set_serial(pfslam_handle *h, int serial);
+int pfslam_debug_check_cells(pfslam_handle *h, long long out[16]);
+int pfslam_set_probe(pfslam_handle *h, int frames);
+int pfslam_get_probe(pfslam_handle *h, unsigned long long *out, int cap_frames, int *n_frames, int *last_ticket);
+const char *pfslam_probe_name(int slot);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
 int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);

@@ -246,7 +246,7 @@ struct pfslam_handle {
     int frame_v2 = 1;             // PFSLAM_FRAME_V2=0: the round-4 frame (A/B runs)
     bool pipe_live = false;       // the last frame was a round-5 frame: its events and ring slots are what the next one waits on
     bool cloud_valid = false;     // the cloud statistics k_motion_count starts from describe the current particles
-    int publish_lag = 1;          // a publishing pass takes the records walked `publish_lag` frames ago (ordered through ev_join)
+    int publish_lag = 2;          // a publishing pass takes the records walked `publish_lag` frames ago (ordered through ev_join)
     int *fs = nullptr;            // frame state words (PF_FS_*)
     int *wcounts = nullptr;       // k_walls: wall cells, new walls, header flags, map size
     int *wall_c2 = nullptr;       // nearest index of every wall of the frame (k_walls -> k_wall_weights)
@@ -257,7 +257,7 @@ struct pfslam_handle {
     short *pgroup = nullptr;      // group-major 16-bit beam-chunk partials
     size_t pgroup_elems = 0;
     hipStream_t fstream = nullptr; // F: the free cells' chain (the round-4 ICP stream's place: a FIFTH stream halves the frame rate on this runtime)
-    hipEvent_t ev_go = nullptr, ev_reduced = nullptr, ev_tree2 = nullptr, ev_order = nullptr, ev_icp = nullptr, ev_ftail = nullptr, ev_shift = nullptr;
+    hipEvent_t ev_reduced = nullptr, ev_tree2 = nullptr, ev_order = nullptr, ev_icp = nullptr, ev_ftail = nullptr, ev_shift = nullptr;
     hipEvent_t ev_marked_r[4] = {nullptr, nullptr, nullptr, nullptr}, ev_walked_r[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr}; // settle(): the tails of C, F, K -> P
     bool shift_pending = false;   // an odometry shift was enqueued behind the last frame: the next ICP solve waits for it

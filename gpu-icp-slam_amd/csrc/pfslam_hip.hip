@@ -249,6 +249,8 @@ struct pfslam_handle {
     int publish_lag = 2;          // a publishing pass takes the records walked `publish_lag` frames ago (ordered through ev_join)
     int *fs = nullptr;            // frame state words (PF_FS_*)
     int *wcounts = nullptr;       // k_walls: wall cells, new walls, header flags, map size
+    float2 *wall_xy2 = nullptr;   // k_walls<1> -> k_walls_traverse -> k_walls<3>: the frame's wall points, the link each falls off, new-wall flags
+    int *wall_leaf2 = nullptr, *wall_new2 = nullptr;
     int *wall_c2 = nullptr;       // nearest index of every wall of the frame (k_walls -> k_wall_weights)
     long long *fstats = nullptr;  // packed min / max keys, [2][4] by ticket parity (a frame's last reduce workgroup resets the other one)
     float *cloud = nullptr;       // cloud statistics {mean x, y, heading, spread}, [2][4] by ticket parity
@@ -260,6 +262,14 @@ struct pfslam_handle {
     hipEvent_t ev_reduced = nullptr, ev_tree2 = nullptr, ev_order = nullptr, ev_icp = nullptr, ev_ftail = nullptr, ev_shift = nullptr;
     hipEvent_t ev_marked_r[4] = {nullptr, nullptr, nullptr, nullptr}, ev_walked_r[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr}; // settle(): the tails of C, F, K -> P
+    int fault = 0;                // PFSLAM_FAULT (tests): see CellPass
+    int stable_order = 0;         // PFSLAM_STABLE_ORDER (tests): a canonical lane order (k_order_stable)
+    int *order_tmp = nullptr;
+    int mark_early = 1;           // the cells' passes start with the lane order (0: behind the frame's reduce)
+    int gates = 1;                // cross-stream edges of a round-5 frame through device words + one-wave gate kernels instead of events (k_gate)
+    int *flags = nullptr;         // PF_FL_*: the ticket of the last frame whose reduce / insert / lane order / ICP solve is done
+    int *gate_err = nullptr, *gate_err_dev = nullptr; // pinned: ticket of a frame one of whose gates gave up (reported by the call that books it)
+    const float *x_frame = nullptr, *y_frame = nullptr, *th_frame = nullptr;
     bool shift_pending = false;   // an odometry shift was enqueued behind the last frame: the next ICP solve waits for it
     bool balance_done = false;    // pfslam_step has already re-balanced for the frame frame_front is about to enqueue
     bool walls_attr_set = false;
@@ -269,10 +279,10 @@ struct pfslam_handle {
 };
 #define PF_PROBE_SLOTS 32
 enum { PB_ICP = 0, PB_MOTION, PB_SCATTER, PB_BOX, PB_MARK, PB_WALK, PB_SCORE, PB_REDUCE, PB_WALLS, PB_UPDATE, PB_WEIGHTS, PB_APPLY, PB_GATHER, PB_RAYS, PB_COUNT,
-       PB_LISTS, PB_FREE, PB_WALLW, PB_REDUCE_LAST, PB_WALLS_KEYS, PB_WALLS_SORTED, PB_WALLS_TRAV, PB_WALLS_END, PB_ICP_SOLVE, PB_ICP_END, PB_END };
+       PB_LISTS, PB_FREE, PB_WALLW, PB_REDUCE_LAST, PB_WALLS_KEYS, PB_WALLS_SORTED, PB_WALLS_TRAV, PB_WALLS_END, PB_WALLS_REP, PB_ICP_SOLVE, PB_ICP_END, PB_UPDATE_END, PB_REDUCE_END, PB_END };
 static const char *const pb_names[PB_END] = {"K icp", "P motion+cells", "P scatter", "K boxes", "K mark", "K walk", "C scan-match", "C reduce", "C walls+insert",
                                              "C cells update", "P weights", "P scan apply", "P sample+gather", "F rays", "F count", "F lists", "F free pass", "F wall weights",
-                                             "C reduce: last wg", "C walls: keys", "C walls: sorted", "C walls: traversed", "C walls: end", "K icp: solve", "K icp: end"};
+                                             "C reduce: last wg", "C walls: keys", "C walls: sorted", "C walls: traversed", "C walls: end", "C walls: traversal launch", "K icp: solve", "K icp: end", "C cells update: last wg ends", "C reduce: last wg ends"};
 static_assert(PB_END <= PF_PROBE_SLOTS, "probe slots");
 
 // ==========================================================================================
@@ -775,6 +785,20 @@ extern "C" void pfslam_default_config(pfslam_config *cfg)
     cfg->balance_period = 100;
 }
 
+// Every event of a handle orders work of ONE device (streams of the handle) or times it; none of them hands memory to the host (frame
+// headers go through explicit system-scope stores, host copies through stream synchronisation).  The default hipEventRecord ends in a
+// SYSTEM-scope release -- an L2 write-back and invalidate that costs the recording stream ~10 us and leaves the kernels behind it cold
+// caches (14 us between two 6 us kernels of the frame's critical chain): a device-scope release is what these events need.
+static hipError_t pf_event_create(hipEvent_t *e, unsigned flags)
+{
+    static const bool dev_scope = !(getenv("PFSLAM_EVENT_SYSTEM") && atoi(getenv("PFSLAM_EVENT_SYSTEM")) != 0); // A/B: 1 = the default (system) release
+    hipError_t rc = hipEventCreateWithFlags(e, flags | (dev_scope ? hipEventReleaseToDevice : 0u));
+    if (rc != hipSuccess && dev_scope) { // (a runtime that does not know the flag)
+        (void)hipGetLastError();
+        rc = hipEventCreateWithFlags(e, flags);
+    }
+    return rc;
+}
 template <typename T>
 static int dalloc(T **p, size_t count)
 {
@@ -806,8 +830,8 @@ static int create_impl(pfslam_handle *h)
     h->kd_cap = cfg->kd_capacity;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
-    HIPCHK(hipEventCreate(&h->ev0));
-    HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(pf_event_create(&h->ev0, 0));
+    HIPCHK(pf_event_create(&h->ev1, 0));
     {
         // the aux streams carry short dependent chains that run BESIDE the scan-match kernel's 131 k single-wave workgroups: at normal
         // priority their workgroups queue behind that flood (the one-workgroup ICP solve: 33 -> 284 us)
@@ -815,19 +839,24 @@ static int create_impl(pfslam_handle *h)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         static const bool prio = !(getenv("PFSLAM_AUX_PRIO") && atoi(getenv("PFSLAM_AUX_PRIO")) == 0);
         HIPCHK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio ? hi : lo));
-        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, lo)); // (beside the scan-match kernel: it must not get in its way)
+        static const int kprio = getenv("PFSLAM_K_PRIO") ? atoi(getenv("PFSLAM_K_PRIO")) : 1; // 0 low, 1 normal (default), 2 high
+        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, kprio == 2 ? hi : kprio == 1 ? (lo + hi) / 2 : lo)); // (beside the scan-match kernel: it must not get in its way)
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_scored, hipEventDisableTiming));
+        HIPCHK(pf_event_create(&h->ev_tree, hipEventDisableTiming));
+        HIPCHK(pf_event_create(&h->ev_scored, hipEventDisableTiming));
         h->fstream = h->istream; // round-5 frames: the free cells' chain (their ICP solve rides on the cells' stream)
         if (const char *e = getenv("PFSLAM_SERIAL")) h->serial = atoi(e) != 0;
         if (const char *e = getenv("PFSLAM_FRAME_V2")) h->frame_v2 = atoi(e) != 0;
-        if (const char *e = getenv("PFSLAM_PUBLISH_LAG")) h->publish_lag = std::min(std::max(atoi(e), 1), 2);
+        if (const char *e = getenv("PFSLAM_GATES")) h->gates = atoi(e) != 0;
+        if (const char *e = getenv("PFSLAM_FAULT")) h->fault = atoi(e);
+        if (const char *e = getenv("PFSLAM_STABLE_ORDER")) h->stable_order = atoi(e) != 0;
+        if (const char *e = getenv("PFSLAM_MARK_EARLY")) h->mark_early = atoi(e) != 0;
+        if (const char *e = getenv("PFSLAM_PUBLISH_LAG")) h->publish_lag = std::min(std::max(atoi(e), 2), 3);
     }
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_mapfork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming));
+    HIPCHK(pf_event_create(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(pf_event_create(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(pf_event_create(&h->ev_mapfork, hipEventDisableTiming));
+    HIPCHK(pf_event_create(&h->ev_map, hipEventDisableTiming));
     const size_t n = h->n, M = (size_t)h->dimx * h->dimy, S = (size_t)h->stride;
     CHK(dalloc(&h->pblk, 3 * S)); CHK(dalloc(&h->pblk2, 3 * S)); CHK(dalloc(&h->w, S)); CHK(dalloc(&h->wm, S));
     HIPCHK(hipMemsetAsync(h->pblk, 0, 3 * S * 4, h->stream));
@@ -1045,7 +1074,7 @@ static int timer_event(pfslam_handle *h, hipEvent_t *e)
 {
     if (h->ev_pending.size() >= 512) CHK(flush_timers(h));
     if (h->ev_pool.empty()) {
-        HIPCHK(hipEventCreate(e));
+        HIPCHK(pf_event_create(e, 0));
     } else {
         *e = h->ev_pool.back();
         h->ev_pool.pop_back();
@@ -1445,7 +1474,8 @@ extern "C" int pfslam_shift_particles(pfslam_handle *h, const float delta[3])
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(join_map(h)); // the map update a frame left on the aux stream reads the pose
     if (h->pipe_live && !h->serial) { // round-5 frames: the pose's readers of the last frame are k_walls (chain) and the free-cell chain
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tree2, 0));
+        HIPCHK(hipEventRecord(h->ev_tail[0], h->aux));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tail[0], 0));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ftail, 0));
     }
     const float ad = delta[2] == delta[2] ? fabsf(delta[2]) : INFINITY;
@@ -1600,9 +1630,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         CHK(dalloc(&h->cell_touched, (size_t)h->max_wall + 1));
         HIPCHK(hipMemsetAsync(h->cell_touched, 0, 4, h->stream));
         CHK(dalloc(&h->fit_acc, (size_t)h->n));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_boxes, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_marked, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_walked, hipEventDisableTiming));
+        HIPCHK(pf_event_create(&h->ev_boxes, hipEventDisableTiming));
+        HIPCHK(pf_event_create(&h->ev_marked, hipEventDisableTiming));
+        HIPCHK(pf_event_create(&h->ev_walked, hipEventDisableTiming));
         HIPCHK(hipMemsetAsync(h->fit_acc, 0, (size_t)h->n * 4, h->stream));
         h->cells_wipe_pending = true;
     }

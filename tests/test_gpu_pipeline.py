@@ -183,8 +183,11 @@ def test_cell_row_bookkeeping_is_deterministic(pkg):
     tree = pkg.kd_create(pts)
     scans = [pkg.synth.make_scan(segs, (0.002 * i, 0.001 * i, 0.0004 * i), seed=2000 + i) for i in range(24)]
     seen = []
+    import os
+    os.environ["PFSLAM_STABLE_ORDER"] = "1"  # (inside a Hilbert cell the counting sort's lane order is atomic arrival order: canonical here)
     for rep in range(3):
         h = pkg.PfSlam(100000, kd_capacity=100000 + (1 << 18))
+        os.environ.pop("PFSLAM_STABLE_ORDER", None) if rep == 2 else None
         h.set_map(tree)
         for f in range(1, 6):
             h.motion_update(f)

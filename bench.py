@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--cloud-sigma", type=float, default=0.0, help="start from a Gaussian cloud of this spread (m; heading: sigma / 8 rad) instead of the dispersed start cloud")
+    ap.add_argument("--topology", type=int, default=0, help="1 | 2: UpdateTopology + CheckLoopClosure inside the frame (kernel.cu:1750-1751; BASELINE configs[4]); "
+                    "the line then carries the graph size and the loop-closure proposals of the last timed frame")
     ap.add_argument("--dry-collectives", action="store_true", help="also time the frame's collectives on their own (per-rank wall times in the line); with one rank: the fields, no traffic")
     return ap.parse_args()
 
@@ -327,6 +329,8 @@ def main():
         e.set_map(tree)
         if a.variant:
             e.set_variant(a.variant)
+        if a.topology:
+            e.set_topology(a.topology)
         # initial condition: a particle cloud already dispersed around the start pose (5 dispersion steps), so that the
         # first scoring launches behave like steady state instead of scoring 100 k coincident particles
         for f in range(1, 6):
@@ -409,6 +413,10 @@ def main():
     eng.set_timing(0)
     trace = eng.trace()
     pose_timed = np.array(eng.pose, np.float32)
+    topo_info = None
+    if a.topology:   # replicated state: every rank holds the same graph and proposes the same pairs
+        nodes_t, idx_t = eng.topology()
+        topo_info = {"mode": a.topology, "nodes": int(len(nodes_t)), "node": int(idx_t), "closures_last_frame": int(len(eng.closures()))}
 
     # ---- census replay: what exactly did the timed launches issue?  A second handle steps through the same frames -- the frame
     # loop is deterministic, so its particles, scans and map are the timed run's, bit for bit (checked on the pose) -- with the
@@ -441,6 +449,8 @@ def main():
                        "frames": "%d..%d (KDTree::Balance falls on frame %% 100 == 5: not inside this window, see long_run)" % (frame - a.steps, frame - 1),
                        "kd_size_end": trace.get("kd_size")},
         }
+        if topo_info is not None:
+            out["config"]["topology"] = topo_info
         if per_rank_s:
             out["per_rank_ms_per_step"] = [v / a.steps * 1e3 for v in per_rank_s[0]]   # each rank's own wall clock over the timed window
         if coll is not None:

@@ -4,7 +4,7 @@
 // gpu-icp-slam_amd/sharded.py runs the same protocol through torch.distributed.
 //
 //   pfslam_mgpu --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX]
-//               [--global-particles G]
+//               [--global-particles G] [--topology 1|2]
 //
 // Launcher mode (no rank in the environment): starts N copies of itself, one per GPU (fork + exec, so no process inherits
 // an initialised HIP / RCCL runtime), and waits for them.  Rank mode: PFSLAM_RANK / PFSLAM_WORLD / PFSLAM_LOCAL_RANK, or the
@@ -77,6 +77,7 @@ static const char *env_any(const char *a, const char *b)
 
 struct Args {
     int gpus = 1, steps = 20, warmup = 5, first_frame = 6;
+    int topology = 0; // --topology 1|2: UpdateTopology + CheckLoopClosure inside the sharded frame (pfslam_set_topology; BASELINE configs[4])
     long global_particles = 0;
     std::string map, scans, dump;
     int particles = 0;
@@ -92,6 +93,7 @@ static bool parse(int argc, char **argv, Args &a)
         else if (s == "--steps") next(a.steps);
         else if (s == "--warmup") next(a.warmup);
         else if (s == "--first-frame") next(a.first_frame);
+        else if (s == "--topology") next(a.topology);
         else if (s == "--global-particles") { if (i + 1 < argc) a.global_particles = atol(argv[++i]); }
         else if (s == "--dump") { if (i + 1 < argc) a.dump = argv[++i]; }
         else pos.push_back(s);
@@ -333,6 +335,7 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
     PF(pfslam_create(&cfg, &R.h));
     PF(pfslam_set_stream(R.h, R.stream));
     if (world > 1) PF(pfslam_set_shard_balance(R.h, 1));
+    if (a.topology) PF(pfslam_set_topology(R.h, a.topology)); // replicated: every rank keeps the same graph, nothing is exchanged for it
     PF(pfslam_set_map(R.h, reinterpret_cast<const pfslam_node *>(map.data()), n_nodes));
     double *scratch = nullptr;
     HIP(hipMalloc((void **)&scratch, 8));
@@ -350,6 +353,22 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
     if (barrier(R, &sec, scratch)) return 1; // MAX over the ranks
     float pose[3];
     PF(pfslam_get_pose(R.h, pose));
+    // topology: the loop-closure proposals of the last frame and the graph, which must be the same on every rank (checked: MAX == MIN of a digest)
+    int n_closures = 0, n_topo = 0, topo_idx = 0;
+    if (a.topology) {
+        PF(pfslam_get_closures(R.h, nullptr, 0, &n_closures));
+        std::vector<float> nodes(3 * 4096);
+        PF(pfslam_get_topology(R.h, nodes.data(), 4096, &n_topo, &topo_idx));
+        double digest = 0.0;
+        for (int k = 0; k < 3 * std::min(n_topo, 4096); k++) digest = digest * 1.000001 + (double)nodes[k];
+        digest += 1e6 * n_closures + 1e3 * topo_idx + n_topo;
+        double hi = digest, lo = -digest;
+        if (barrier(R, &hi, scratch) || barrier(R, &lo, scratch)) return 1;
+        if (hi != -lo) {
+            fprintf(stderr, "[rank %d] the ranks' topology graphs differ\n", rank);
+            return 3;
+        }
+    }
     if (!a.dump.empty()) {
         const pfslam_particle *p;
         const pfslam_node *nd;
@@ -365,9 +384,9 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
                "\"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, \"dtype\": \"f32\", \"data\": \"synthetic\", "
                "\"config\": {\"workload\": \"1081-beam scans, %d particles/GPU, %d-point KD map, full SLAM step\", \"particles_global\": %ld, "
                "\"parallelism\": \"particles sharded x%d, map replicated\", \"kd_size_end\": %d, \"driver\": \"C++ / librccl (host/pfslam_mgpu.cpp)\", "
-               "\"collectives\": %d, \"pose\": [%.9g, %.9g, %.9g]}}\n",
+               "\"collectives\": %d, \"topology\": {\"mode\": %d, \"nodes\": %d, \"node\": %d, \"closures_last_frame\": %d}, \"pose\": [%.9g, %.9g, %.9g]}}\n",
                (double)G * a.steps / sec, world, a.steps, a.warmup, sec / a.steps * 1e3, stride, n_nodes, G, world, pfslam_kd_size(R.h),
-               R.collectives, pose[0], pose[1], pose[2]);
+               R.collectives, a.topology, n_topo, topo_idx, n_closures, pose[0], pose[1], pose[2]);
         fflush(stdout);
     }
     PF(pfslam_destroy(R.h));
@@ -381,7 +400,7 @@ int main(int argc, char **argv)
     Args a;
     if (!parse(argc, argv, a)) {
         printf("Usage: %s --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX] "
-               "[--global-particles G]\n", argv[0]);
+               "[--global-particles G] [--topology 1|2]\n", argv[0]);
         return 1;
     }
     const char *rk = env_any("PFSLAM_RANK", "RANK");

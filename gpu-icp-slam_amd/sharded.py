@@ -113,6 +113,25 @@ class ShardedSlam:
     def trace(self): return self.eng.trace()   # books the frames in flight first (pfslam_get_trace)
     @property
     def pose(self): return self.eng.pose
+    @property
+    def kd_size(self): return self.eng.kd_size
+
+    # -- BASELINE configs[4]: the topology graph and the loop-closure proposals (UpdateTopology / CheckLoopClosure, kernel.cu:623-795,
+    # call sites 1750-1751) inside the SHARDED frame.  Both read only replicated state -- the frame's pose and the 2-D grid --, so every
+    # rank keeps the same graph and proposes the same pairs; nothing is exchanged for them.
+    def set_topology(self, mode=1):
+        """1 = at the end of every frame (the frame is booked at once), 2 = with the booking of the frame, one step late."""
+        self.eng.set_topology(mode)
+    def closures(self): return self.eng.closures()
+    def topology(self): return self.eng.topology()
+    def map(self): return self.eng.map()
+    def shift_particles(self, delta):
+        """Odometry increment: every pose of every shard and the (replicated) robot pose move by the same (dx, dy, dtheta)."""
+        self.eng.shift_particles(delta)
+    def set_particles(self, p_global):
+        """The GLOBAL particle array (every rank passes the same one); this rank keeps its shard."""
+        self.eng.set_particles(np.ascontiguousarray(p_global[self.goff:self.goff + self.n]))
+    def particles(self): return self.eng.particles()   # this rank's shard
 
     def _all_gather(self, dst, src, async_op=False):
         """Returns a work handle when async_op (wait() it before the result is used), else None."""

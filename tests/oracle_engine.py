@@ -97,6 +97,9 @@ class OracleShardEngine:
         self.src = None
         self.icp_delta = None
         self.external, self.builds, self.adopted = False, 0, 0
+        # topology graph + loop-closure proposals inside the frame (replicated: pose and 2-D grid only; the KD frame never writes the grid)
+        self.topo_mode, self.topo, self._closures = 0, None, np.zeros((0, 2), np.int32)
+        self.grid = None
 
     # ---- helpers
     def _aos(self):
@@ -117,6 +120,23 @@ class OracleShardEngine:
     def kd_size(self): return self.size
     @property
     def pose(self): return self.robot.copy()
+
+    def set_topology(self, mode=1):
+        self.topo_mode = int(mode)
+        if self.topo is None:
+            self.topo = O.Topology()
+            p = O.default_patch()
+            dim = int(np.float32(p.scale_x) / np.float32(p.res_x))
+            self.grid = np.full((dim, dim), -100, np.int8)
+    def closures(self): return self._closures.copy()
+    def topology(self): return self.topo.nodes(), self.topo.node_idx
+    def map(self): return self.tree[:self.size].copy()
+    def particles(self): return self._aos()
+    def set_particles(self, p): self._from_aos(p); self.wm[:] = p["w"]
+    def shift_particles(self, delta):
+        d = np.ascontiguousarray(delta, np.float32)
+        self.x += d[0]; self.y += d[1]; self.th += d[2]
+        self.robot += d
 
     def maybe_balance(self, frame):
         if self.period > 0 and frame % self.period == 5 and self.size > 0:
@@ -213,6 +233,9 @@ class OracleShardEngine:
         if did:
             self.resample_gather()
         self._trace.update(resampled=did, neff=neff, kd_size=self.size)
+        if self.topo_mode:  # //UpdateTopology(); //CheckLoopClosure(); (kernel.cu:1750-1751)
+            self.topo.update(self.robot)
+            self._closures = self.topo.loop_closure(self.grid, self.robot)
 
     def trace(self):
         return dict(self._trace)

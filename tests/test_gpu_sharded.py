@@ -168,3 +168,100 @@ def test_two_processes_one_gpu_gloo_match_single_handle(tmp_path, pkg):
     for fld, key in (("x", "x"), ("y", "y"), ("theta", "th"), ("w", "w")):
         assert (bits(np.concatenate([r[k][key] for k in range(world)])) == bits(want[fld])).all(), fld
     a.close()
+
+
+class _VirtualRanks:
+    """`world` sharded handles on one GPU stepped as ONE engine: the three all-gathers of the frame done by hand on the zero-copy
+    views (the protocol of ShardedSlam.step), every rank's pose / trace / closures / graph checked against rank 0's."""
+
+    def __init__(self, pkg, torch, n_global, world, **kw):
+        sharded = importlib.import_module("gpu-icp-slam_amd.sharded")
+        self.torch, self.n_global = torch, n_global
+        self.lay = [sharded.shard_layout(n_global, world, r) for r in range(world)]
+        self.engs = [pkg.PfSlam(cnt, global_offset=off, global_n=n_global, shard_stride=stride, **kw) for stride, off, cnt in self.lay]
+        self.bufs = [sharded.GpuBuffers(e, torch, 0) for e in self.engs]
+
+    def _sync(self):
+        for e in self.engs:
+            e.synchronize()
+        self.torch.cuda.synchronize()
+
+    def set_topology(self, mode):
+        for e in self.engs:
+            e.set_topology(mode)
+
+    def shift_particles(self, d):
+        for e in self.engs:
+            e.shift_particles(d)
+
+    def step(self, f, scan):
+        torch, engs, bufs = self.torch, self.engs, self.bufs
+        seeded = [e.shard_disperse(f, scan) for e in engs]
+        assert len(set(seeded)) == 1
+        if seeded[0]:
+            return
+        self._sync()
+        blocks = [b.pose_blocks() for b in bufs]
+        g = torch.cat([loc for loc, _ in blocks])
+        for _, glob in blocks:
+            glob.copy_(g)
+        self._sync()
+        for e in engs:
+            e.shard_score()
+        self._sync()
+        packs = torch.cat([b.pack for b in bufs])
+        for b in bufs:
+            b.packs.copy_(packs)
+        self._sync()
+        for e in engs:
+            e.shard_weights()
+        self._sync()
+        gw = torch.cat([b.w for b in bufs])
+        for b in bufs:
+            b.gw.copy_(gw)
+        self._sync()
+        for e in engs:
+            e.shard_finish()
+
+    def _same(self, fn):
+        vals = [fn(e) for e in self.engs]
+        for v in vals[1:]:
+            assert repr(v) == repr(vals[0])
+        return vals[0]
+
+    def trace(self): return self._same(lambda e: e.trace())
+
+    @property
+    def pose(self):
+        self._same(lambda e: np.asarray(e.pose, np.float32).view(np.int32).tolist())
+        return self.engs[0].pose
+
+    def closures(self):
+        self._same(lambda e: e.closures().tolist())
+        return self.engs[0].closures()
+    def topology(self): return self.engs[0].topology()
+    def close(self):
+        for e in self.engs:
+            e.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sharded_frames_with_topology_match_the_single_handle(pkg, mode):
+    """BASELINE configs[4] on the product: the free-running closed loop (tests/loop_scenario.py: odometry shifts, topology graph and
+    loop-closure proposals inside the frame) on three virtual ranks of one GPU against ONE handle stepping the same 20 000 particles:
+    every frame's pose, map size, resample flag and proposals, and the final graph; every rank keeps the same graph."""
+    torch = pytest.importorskip("torch")
+    import loop_scenario as LS
+    n, world, n_frames = 20000, 3, LS.N_FRAMES
+    scans = LS.scans(pkg, n_frames=n_frames)
+    one = pkg.PfSlam(n, kd_capacity=1 << 18)
+    want = LS.run_free(one, scans, n_frames=n_frames, look_every=1 if mode == 1 else 4, topology_mode=mode)
+    want_graph = one.topology()
+    v = _VirtualRanks(pkg, torch, n, world, kd_capacity=1 << 18)
+    got = LS.run_free(v, scans, n_frames=n_frames, look_every=1 if mode == 1 else 4, topology_mode=mode)
+    assert got == want
+    for e in v.engs:
+        nodes, idx = e.topology()
+        assert idx == want_graph[1] and (np.asarray(nodes, np.float32).view(np.int32) == np.asarray(want_graph[0], np.float32).view(np.int32)).all()
+    assert sum(len(r[3]) for r in want) > 100   # the loop closes: proposals were made
+    one.close(); v.close()

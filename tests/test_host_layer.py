@@ -212,9 +212,10 @@ def test_cpp_rccl_driver_world1_is_bit_identical_to_pfslam_step(tmp_path, pkg, p
         env.pop(k, None)
     out = subprocess.check_output([os.path.join(HOST, "pfslam_mgpu"), "--gpus", "1", str(tmp_path / "map.nodes"), str(tmp_path / "scans.f32"),
                                    str(particles), "--steps", str(n_steps), "--warmup", str(n_warm), "--first-frame", "6",
-                                   "--dump", str(tmp_path / "out")], env=env, timeout=300).decode()
+                                   "--dump", str(tmp_path / "out"), "--topology", "1"], env=env, timeout=300).decode()
     d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
     h = pkg.PfSlam(particles, kd_capacity=len(tree) + (1 << 18))
+    h.set_topology(1)   # (--topology 1: UpdateTopology + CheckLoopClosure inside the sharded frame as well, BASELINE configs[4])
     h.set_map(tree)
     for f in range(1, 6):
         h.motion_update(f)
@@ -231,6 +232,8 @@ def test_cpp_rccl_driver_world1_is_bit_identical_to_pfslam_step(tmp_path, pkg, p
         assert (got[fld].view(np.int32) == want[fld].view(np.int32)).all(), fld
     assert (tmp_path / "out.rank0.nodes").read_bytes() == h.map().tobytes()
     assert (np.array(d["config"]["pose"], np.float32).view(np.int32) == h.pose.view(np.int32)).all()
+    nodes, idx = h.topology()
+    assert d["config"]["topology"] == {"mode": 1, "nodes": len(nodes), "node": idx, "closures_last_frame": len(h.closures())}
     h.close()
 
 

@@ -78,6 +78,50 @@ def test_ranks_match_unsharded_oracle(tmp_path, pkg, oracle, strict, world, n_gl
     o.close()
 
 
+def _loop_worker(rank, world, port, out_dir, n_frames):
+    """BASELINE configs[4] as written: the loop-closure run SHARDED, with the topology graph / loop-closure proposals inside the frame."""
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import loop_scenario as LS
+    import oracle_engine as OE
+    import oracle_lib as O
+    pkg = importlib.import_module("gpu-icp-slam_amd")
+    sharded = importlib.import_module("gpu-icp-slam_amd.sharded")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n_global = LS.N_PARTICLES
+    stride, goff, n = sharded.shard_layout(n_global, world, rank)
+    eng = OE.OracleShardEngine(n, goff, n_global, kd_capacity=1 << 18, stride=stride)
+    s = sharded.ShardedSlam(pkg, n_global, rank, world, dist=dist, torch=torch, engine=eng, buffers=OE.OracleBuffers(eng))
+    mk = lambda p: O.make_particles(n_global, float(p[0]), float(p[1]), float(p[2]))
+    rec = LS.run(s, mk, LS.scans(pkg, n_frames=n_frames), n_frames=n_frames)
+    nodes, idx = s.topology()
+    from make_golden_v3 import pack_records
+    frames, pairs = pack_records(rec)
+    np.savez(os.path.join(out_dir, "loop%d.npz" % rank), frames=frames, pairs=pairs, nodes=np.asarray(nodes, np.float32), idx=idx, tree=s.map())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_loop_closure_run_matches_golden_v3(tmp_path, pkg, world):
+    """configs[4]: the 260-frame closed loop with UpdateTopology / CheckLoopClosure in the frame (kernel.cu:1750-1751), particles sharded
+    over 2 and 4 ranks: every rank reproduces the committed fixture of the UNSHARDED oracle -- per-frame pose bits, map size, resample
+    flags, loop-closure proposals, the topology graph -- and all ranks end with the same map."""
+    import loop_scenario as LS
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_v3.npz"))
+    n_frames = LS.N_FRAMES
+    mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path), n_frames), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "loop%d.npz" % k)) for k in range(world)]
+    for k in range(world):
+        bad = np.flatnonzero((r[k]["frames"] != gold["kd_frames"]).any(1))
+        assert len(bad) == 0, "rank %d: frame %d differs: got %s want %s" % (k, bad[0] + 1, r[k]["frames"][bad[0]], gold["kd_frames"][bad[0]])
+        assert (r[k]["pairs"] == gold["kd_pairs"]).all()
+        assert int(r[k]["idx"]) == int(gold["kd_topo_idx"]) and (r[k]["nodes"].view(np.int32) == gold["kd_topo"].view(np.int32)).all()
+        assert r[k]["tree"].tobytes() == r[0]["tree"].tobytes()
+    assert (gold["kd_frames"][:, 6] > 0).sum() > 50   # the run does propose closures
+
+
 def test_key_packing_orders_like_minmax_element():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_engine as OE

@@ -143,6 +143,30 @@ def pmc_busy(pmc, avgp, name, units, clock_ghz, quad):
     return v * (4.0 if quad else 1.0) / units / (ms * 1e-3 * clock_ghz * 1e9)
 
 
+def valu_mix_busy(pmc, avgp, cus, clock_ghz):
+    """VALU issue cycles of the scan-match kernel, mix-weighted: SQ_INSTS_VALU_* counts x the measured cost of each kind
+    (profiles/rNN_valu_calibration.json, tools/valu_calibrate.sh) / SIMDs / kernel cycles.  INT32 mixes 2.4-cycle adds and 4.2-cycle
+    shifts / bit-field ops: bracketed."""
+    try:
+        cal_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_calibration.json")))
+        if not cal_files or not clock_ghz:
+            return None
+        kinds = json.load(open(cal_files[-1]))["kinds"]
+        c = lambda name: kinds[name]["cycles_per_wave_instruction_per_simd"]
+        fast, slow = (c("v_fma_f32") + c("v_mul_f32") + c("v_add_f32")) / 3.0, (c("v_cndmask_b32") + c("v_cvt_f32_i32") + c("v_fma_f64") + c("v_mul_f64")) / 4.0
+        total = avgp["SQ_INSTS_VALU"]
+        f32 = avgp.get("SQ_INSTS_VALU_ADD_F32", 0.0) + avgp.get("SQ_INSTS_VALU_MUL_F32", 0.0) + avgp.get("SQ_INSTS_VALU_FMA_F32", 0.0)
+        i32 = avgp.get("SQ_INSTS_VALU_INT32", 0.0)
+        rest = total - f32 - i32
+        ms = (pmc.get("pass_kernel_ms") or {}).get("SQ_INSTS_VALU") or pmc.get("kernel_ms")
+        cycles = ms * 1e-3 * clock_ghz * 1e9 * 4.0 * cus
+        return {"lo": (f32 * fast + i32 * fast + rest * slow) / cycles, "hi": (f32 * fast + i32 * slow + rest * slow) / cycles,
+                "cycles_fp32_add_mul_fma": fast, "cycles_other": slow, "insts_fp32_add_mul_fma": f32, "insts_int32": i32, "insts_other": rest,
+                "calibration": os.path.relpath(cal_files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def find_pmc(explicit, n_local, map_points):
     """Newest committed rocprofv3 PMC summary of k_score_kd for THIS workload (profiles/rNN_pmc_score_kd*.json)."""
     if explicit:
@@ -269,6 +293,9 @@ def self_launch(n):
 
 
 def main():
+    if os.environ.get("PFSLAM_BENCH_WATCHDOG"):  # debugging aid: every thread's traceback after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PFSLAM_BENCH_WATCHDOG"]), exit=True)
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         if not a.same_device:
@@ -297,6 +324,7 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: the bootstrap over loopback (the container's other interfaces may not route)
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -309,7 +337,7 @@ def main():
     tree = pkg.kd_create(pts)
     long_run = not a.no_cpu_baseline
     # long-run leg: filler up to the next frame % 100 == 6, 100 timed frames, 20 frames for the phase split
-    n_frames = a.warmup + a.steps + (((6 - (FIRST_FRAME + a.warmup + a.steps)) % 100) + 100 + 20 if long_run else 0)
+    n_frames = a.warmup + 2 * a.steps + (((6 - (FIRST_FRAME + a.warmup + a.steps)) % 100) + 100 + 20 if long_run else 0)   # (+ steps: the frame-probe leg)
 
     def one_scan(f):
         return pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f)
@@ -418,6 +446,33 @@ def main():
         nodes_t, idx_t = eng.topology()
         topo_info = {"mode": a.topology, "nodes": int(len(nodes_t)), "node": int(idx_t), "closures_last_frame": int(len(eng.closures()))}
 
+    # ---- where the frame's time goes: the next `steps` frames on the SAME handle with the frame probe on (pfslam_set_probe: the first thread
+    # of every launch of a round-5 frame stores the wall clock; no events, no profiler) -- outside the timed region
+    frame_probe, probe_frames = None, 0
+    if not distributed:
+        try:
+            e0.set_probe(a.steps + 8)
+            for k in range(a.steps):
+                eng.step(frame, scans[a.warmup + a.steps + k]); frame += 1; probe_frames += 1
+            eng.synchronize()
+            names, tp, _ = e0.probe(a.steps)
+            e0.set_probe(0)
+            if len(tp) and "C scan-match" in names:
+                sc, rd = names.index("C scan-match"), names.index("C reduce")
+                ok = (tp[:, sc] > 0) & (tp[:, rd] > 0)
+                good = ok[1:] & ok[:-1]
+                if good.any():
+                    chain = (tp[1:, sc] - tp[:-1, rd])[good]
+                    rel = np.where(tp > 0, tp - tp[:, sc:sc + 1], np.nan)
+                    frame_probe = {"frames": int(good.sum()), "chain_us_mean": float(chain.mean()), "chain_us_min": float(chain.min()), "chain_us_max": float(chain.max()),
+                                   "scan_match_start_to_next_us": float((tp[1:, sc] - tp[:-1, sc])[good].mean()),
+                                   "launch_start_us_after_scan_match_start": {names[k]: float(np.nanmean(rel[:, k])) for k in range(len(names)) if not np.all(np.isnan(rel[:, k]))},
+                                   "note": "chain = start of a frame's reduce -> start of the next frame's scan-match kernel: what sits between two scan-match "
+                                           "kernels (reduce, walls + insert, cell rows, the edge to the particle chain); wall-clock stamps of the launches' first "
+                                           "threads over the %d frames BEHIND the timed window, same handle" % a.steps}
+        except Exception as e:  # the probe must never break the contract line
+            frame_probe = {"error": repr(e)}
+
     # ---- census replay: what exactly did the timed launches issue?  A second handle steps through the same frames -- the frame
     # loop is deterministic, so its particles, scans and map are the timed run's, bit for bit (checked on the pose) -- with the
     # counting instantiation of the scan-match kernel behind every scoring pass (pfslam_set_census).  Every rank takes part.
@@ -451,6 +506,8 @@ def main():
         }
         if topo_info is not None:
             out["config"]["topology"] = topo_info
+        if frame_probe is not None:
+            out["frame"] = frame_probe
         if per_rank_s:
             out["per_rank_ms_per_step"] = [v / a.steps * 1e3 for v in per_rank_s[0]]   # each rank's own wall clock over the timed window
         if coll is not None:
@@ -492,7 +549,12 @@ def main():
         gather_bytes = float(np.mean(gbytes))                  # lane-level bytes the TA path moves per launch
         lane_visits = float(np.mean([c["visits"] for c in cen_timed])) if cen_timed else 0.0
         trips = float(np.mean([c["trips"] for c in cen_timed])) if cen_timed else 0.0
-        achieved = gather_bytes / kern_s / 1e9
+        # every wave gather priced as ONE request of the gather path (16 B x 64 lanes): a wave gather costs the texture addresser the same ~16
+        # cycles whatever its width (profiles/r01_ubench_gather_rate.txt), and this is what a reader recomputes from the hardware counter
+        # alone (TA_BUFFER_READ_WAVEFRONTS_sum x 1024 B / kernel time / peak).  The lane-level bytes (4-byte table words as 4 bytes) are kept
+        # beside it as frac_lane_bytes.
+        achieved_lane = gather_bytes / kern_s / 1e9
+        achieved = (g16 + g4) * 1024.0 / kern_s / 1e9
         peak_measured = ub["wave_gathers_per_s"] * 1024.0 / 1e9
         pmc_path = find_pmc(a.pmc_file, n_local, a.map_points)
         traffic, clock_ghz, pmc, avgp = None, None, None, {}
@@ -514,10 +576,10 @@ def main():
         out["roofline"] = {
             "bound": "l1_gather", "achieved": achieved, "peak": peak_measured, "unit": "GB/s", "frac": achieved / peak_measured,
             "traffic": traffic,
+            "traffic_source": ("replayed from " + os.path.relpath(pmc_path, ROOT) + " (rocprofv3 PMC passes of this command on another lease; not measured in this run)") if pmc_path else None,
             "frac_of_nominal_peak": achieved / peak_nominal,
-            # every wave gather priced as a full 16-byte one (a hardware counter cannot tell the 4-byte parent-index gathers apart):
-            # the figure a reader recomputes from profiles/ alone as TA_BUFFER_READ_WAVEFRONTS_sum x 1024 B / kernel_ms / peak
-            "frac_all_gathers_as_16B": (g16 + g4) * 1024.0 / kern_s / 1e9 / peak_measured,
+            "frac_lane_bytes": achieved_lane / peak_measured, "achieved_lane_bytes": achieved_lane,
+            "frac_all_gathers_as_16B": achieved / peak_measured,  # (= frac since round 5; the key of rounds 3-4 is kept)
             "peak_nominal": peak_nominal, "peak_nominal_clock_ghz": ghz,
             "peak_nominal_clock_source": ("GRBM_GUI_ACTIVE / 8 / kernel time of " + os.path.relpath(pmc_path, ROOT)) if clock_ghz else "nominal clock (hipDeviceProp)",
             "kernel": "k_score_kd_cells" if cell_stats["rows"] else "k_score_kd_plan" if plan_stats["rows"] else "k_score_kd",
@@ -549,16 +611,21 @@ def main():
                          note="shared-prefix plan of the LAST timed launch (pfslam_plan_stats): one planning lane per (wave, beam) walks "
                               "the root path common to the wave's 64 queries and keeps only the nodes that can be nearest for some "
                               "lane; kernel_ms = k_group_box + k_plan, which run before the scan-match kernel"),
-            "definition": "achieved = lane-level bytes of the wave gathers one timed launch issues (16 B x 64 lanes per node-record gather, "
-                          "4 B x 64 per parent-index gather; census of the timed launches, mean) / HIP-event time of the same launches "
-                          "(mean); peak = wave-gather rate of this chip measured in this process (pfslam_ubench_gather: cache-resident "
+            "definition": "achieved = wave gathers one timed launch issues (census of the timed launches, mean) x 1024 B (every wave gather "
+                          "as one 16 B x 64 lanes request of the gather path, whatever its width) / HIP-event time of the same launches "
+                          "(mean); frac_lane_bytes prices the 4-byte gathers (cell-table words, parent indices) at 256 B instead; peak = wave-gather rate of this chip measured in this process (pfslam_ubench_gather: cache-resident "
                           "table, 8 waves/SIMD) x 1024 B; frac_of_nominal_peak prices the same bytes against CUs x 64 B/clk x clock.  "
                           "The cell-row kernel of round 3 replaced the per-query tree walk by a handful of row slots per query, and what "
-                          "binds it now is the vector ALUs and the gather path together (pmc.valu_busy_measured, pmc.ta_busy): `frac` says how much of the gather path it still uses, "
+                          "binds it now is the vector ALUs and the gather path together (pmc.valu_issue_busy_mix_weighted, pmc.ta_busy): `frac` says how much of the gather path it still uses, "
                           "not how far it is from its own ceiling",
             "ubench": dict(ub, note="the measured rate is what the same gather instruction sustains on this box, wave-uniform addresses"),
             "pmc": None if not pmc else {
-                "source": os.path.relpath(pmc_path, ROOT), "measured_clock_ghz": clock_ghz,
+                "source": os.path.relpath(pmc_path, ROOT), "replayed": True,
+                "replayed_note": "every field of this block is computed from the committed rocprofv3 summary named in `source` (PMC passes of `python bench.py "
+                                 "--no-cpu-baseline` on another lease, tools/profile_round.sh), NOT measured in this run; measured live in this run: ms_per_step, "
+                                 "kernel_ms, the census, ubench, frame",
+                "measured_clock_ghz": clock_ghz,
+                "valu_issue_busy_mix_weighted": valu_mix_busy(pmc, avgp, ub["cus"], clock_ghz),
                 "ta_buffer_read_wavefronts_per_launch": ta_wf,
                 "census_over_pmc_wavefronts": ((g16 + g4) / ta_wf) if ta_wf else None,
                 "ta_busy": (avgp["TA_TA_BUSY_sum"] / ub["cus"] / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("TA_TA_BUSY_sum") and avgp.get("GRBM_GUI_ACTIVE") else None,
@@ -567,7 +634,7 @@ def main():
                 "valu_issue_frac_if_4_cycles_each": (4.0 * (avgp.get("SQ_INSTS_VALU", 0.0) / (4.0 * ub["cus"])) / (avgp["GRBM_GUI_ACTIVE"] / 8.0)) if avgp.get("GRBM_GUI_ACTIVE") else None,
                 # MEASURED busy cycles (round 4): SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends executing vector ALU instructions
                 # (rocprofiler's VALUBusy = 4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles); cycles = that pass's own kernel time x the measured clock
-                "valu_busy_measured": pmc_busy(pmc, avgp, "SQ_ACTIVE_INST_VALU", 4.0 * ub["cus"], clock_ghz, quad=True),
+                "sq_active_inst_valu_over_insts_valu": (avgp["SQ_ACTIVE_INST_VALU"] / avgp["SQ_INSTS_VALU"]) if avgp.get("SQ_ACTIVE_INST_VALU") and avgp.get("SQ_INSTS_VALU") else None,
                 "vmem_issue_busy_measured": pmc_busy(pmc, avgp, "SQ_ACTIVE_INST_VMEM", 4.0 * ub["cus"], clock_ghz, quad=True),
                 "scalar_busy_measured": pmc_busy(pmc, avgp, "SQ_ACTIVE_INST_SCA", 4.0 * ub["cus"], clock_ghz, quad=True),
                 "sq_busy_measured": pmc_busy(pmc, avgp, "SQ_BUSY_CYCLES", 32.0, clock_ghz, quad=False),
@@ -584,9 +651,12 @@ def main():
                         "correction of MI355X_MICROARCH.md) -- the map records are cache resident, compulsory HBM traffic is ~20 B per "
                         "evaluation; census_over_pmc_wavefronts compares this run's census with the counter (1.0 = agreement; the census "
                         "also counts the parent-index reads of the generic tail, global loads a BUFFER counter does not see); "
-                        "valu_busy_measured = 4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles (the counter is in quad-cycles: rocprofiler's VALUBusy), "
-                        "the share of a SIMD's cycles spent executing vector ALU instructions -- MEASURED; valu_issue_frac_if_4_cycles_each "
-                        "is the round-3 estimate (every VALU instruction priced at 4 cycles) kept beside it; sq_busy_measured = "
+                        "SQ_ACTIVE_INST_VALU ticks ONCE per VALU instruction on this part (sq_active_inst_valu_over_insts_valu = 1.00; the same in "
+                        "every kind of tools/ubench/valu_rate, profiles/r05_valu_calibration.json), so '4 x the counter' is an instruction count "
+                        "priced at 4 cycles, not a busy measurement (it gives 1.68 for a pure v_fma_f32 stream); valu_issue_busy_mix_weighted = the "
+                        "instruction counts by kind (SQ_INSTS_VALU_*) x the cycles per wave-instruction per SIMD MEASURED for each kind by that "
+                        "calibration (fp32 add / mul / fma 2.4, everything else 4.2; the INT32 class holds both kinds: lo / hi) / SIMDs / the kernel's "
+                        "cycles; valu_issue_frac_if_4_cycles_each is the round-3 estimate kept beside it; sq_busy_measured = "
                         "SQ_BUSY_CYCLES / 32 shader engines x XCDs / cycles"},
             "alg_equiv": {"bytes_per_eval": alg_bytes_per_eval, "mean_node_visits": vbar, "valid_beams": bvalid,
                           "GBs": alg_bytes_per_eval * n_local / kern_s / 1e9,
@@ -597,7 +667,7 @@ def main():
     # ---- the same step over a whole balance cycle (every rank takes part; rank 0 reports) ----------
     if long_run:
         # continue to the next frame % 100 == 6, then time exactly 100 frames: one KDTree::Balance (frame % 100 == 5) inside
-        k = a.warmup + a.steps
+        k = a.warmup + a.steps + probe_frames
         while frame % 100 != 6:
             eng.step(frame, scans[k]); frame += 1; k += 1
         if k + 100 <= n_frames:

@@ -888,7 +888,7 @@ static int create_impl(pfslam_handle *h)
     CHK(dalloc(&h->cells, (size_t)2 * PF_CELLS_MAX + PF_CELLS_MAX / 1024));
     HIPCHK(hipMemsetAsync(h->cells, 0, ((size_t)2 * PF_CELLS_MAX + PF_CELLS_MAX / 1024) * sizeof(int), h->stream));
     CHK(dalloc(&h->stats, 8)); CHK(dalloc(&h->pose, 4)); CHK(dalloc(&h->start, 4));
-    CHK(dalloc(&h->icp_tar, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_cor, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_dbg, 32));
+    CHK(dalloc(&h->icp_tar, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_cor, (size_t)h->nb * 4)); CHK(dalloc(&h->icp_dbg, 64)); // (round-5 frames: two of them, by ticket parity)
     CHK(dalloc(&h->free_mask, 2 * M)); // the two masks are contiguous: one memset per frame
     h->wall_mask = h->free_mask + M;
     h->max_wall = h->nb;
@@ -1498,7 +1498,9 @@ static int score_chunks(const pfslam_handle *h)
     // ~16 rounds of the 8192 wave slots (256 CUs x 32): fine-grained enough that the tail of the last round is
     // small (measured: 16 k waves 3.33 ms, 128 k waves 2.9-3.0 ms at 100 k particles); down to one beam per chunk for small N
     const int groups = (h->n + 63) / 64;
-    static const int target = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 131072;
+    // (round 5: 65 536 -- 42 chunks of 26 beams at 100 k particles.  A wave's prologue, the fp64 sincos of its 64 headings, is ~10 % of a
+    // 13-beam chunk, and the reduce reads half the partials: frame 0.530 -> 0.520 ms in an A/B on one box; 32 768: 0.538, 262 144: 0.569)
+    static const int target = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 65536;
     int chunks = (target + groups - 1) / groups;
     chunks = std::max(1, std::min(chunks, h->nb)); // small particle counts go down to one beam per wave
     // Beam-chunk partials added afterwards equal the reference's sequential beam-order float sum only when every term is an

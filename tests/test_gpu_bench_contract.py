@@ -34,7 +34,8 @@ def test_bench_json_line_has_contract_fields():
     assert g["wave_gathers_16B_per_launch"] > 0 and 1.0 <= g["lanes_active_per_trip"] <= 64.0
     b = g["gather_bytes_per_launch"]
     assert 0 < b["min"] <= b["mean"] <= b["max"]
-    assert abs(r["achieved"] - b["mean"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+    assert abs(r["achieved_lane_bytes"] - b["mean"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved_lane_bytes"] < 1e-9
+    assert abs(r["achieved"] - g["wave_gathers_per_launch"] * 1024.0 / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9   # every wave gather as 16 B x 64
     assert r["ubench"]["wave_gathers_per_s"] > 1e9 and r["ubench"]["cus"] >= 1
     assert r["pmc"] is None                                       # no committed PMC summary for this small test workload
     assert r["traffic"] is None
@@ -54,7 +55,17 @@ def _torchrun(nproc, port, *bench_args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3",
            "--warmup", "1", "--particles", "4096", "--map-points", "20000"] + list(bench_args)
-    out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600).decode()
+    # (the process-group bootstrap has been seen to hang on some leases -- 2 of 6 boxes in round 5, never reproducible on the same box
+    # twice, with and without this round's changes --: a watchdog inside bench.py, a bounded wait here, and one retry on a fresh port)
+    out = None
+    for attempt in range(2):
+        cmd[cmd.index("--master-port") + 1] = str(port + 20 * attempt)
+        try:
+            out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=300, env=dict(os.environ, PFSLAM_BENCH_WATCHDOG="240")).decode()
+            break
+        except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
+            last = e
+    assert out is not None, getattr(last, "output", b"")[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
@@ -117,6 +128,13 @@ def test_roofline_census_agrees_with_committed_pmc():
     # the counter agrees with the census to 10 % (above); the two KERNEL TIMES are from different runs, and since the cell rows persist
     # the scan-match kernel's time differs by up to ~10 % from run to run on one box (tools/experiments/r04/README.md): 20 %
     assert abs(frac_pmc / r["frac_all_gathers_as_16B"] - 1.0) < 0.20, (frac_pmc, r["frac_all_gathers_as_16B"])
-    # the 4-byte gathers (cell-table words, parent indices) priced as 16-byte ones: a third of all wave gathers once the corner test
-    # has left most rows with a single 16-byte slot
-    assert r["frac"] <= r["frac_all_gathers_as_16B"] <= 1.6 * r["frac"]
+    # round 5: `frac` itself prices every wave gather as one 16 B x 64 lanes request (what the counter sees); the lane-level bytes --
+    # the 4-byte gathers (cell-table words, parent indices: a third of all wave gathers) at 256 B -- stay beside it
+    assert r["frac"] == r["frac_all_gathers_as_16B"] and r["frac_lane_bytes"] <= r["frac"] <= 1.6 * r["frac_lane_bytes"]
+    # the pmc block says that it is replayed from profiles/, and its VALU figure is the calibrated one (no assumed cycle count)
+    assert p["replayed"] is True and p["source"].startswith("profiles/")
+    v = p["valu_issue_busy_mix_weighted"]
+    assert v and 0.3 < v["lo"] <= v["hi"] < 1.0 and v["calibration"].startswith("profiles/")
+    assert abs(p["sq_active_inst_valu_over_insts_valu"] - 1.0) < 0.02
+    # where the frame's time goes, from the frame's own kernels
+    assert d["frame"]["frames"] >= 10 and 60.0 < d["frame"]["chain_us_mean"] < 170.0, d["frame"]

@@ -54,6 +54,16 @@ __global__ __launch_bounds__(256) void k_valu(int iters, float *out)
                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(m) : "v"(b));))
         }
     }
+    if (OP >= 11 && OP <= 13) { // fp64: the end point of the scan-match kernel (sincos_sum_spec) is 14 of these per (lane, beam)
+        double d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, db = 1.0000001, dc = 1e-30;
+        for (int it = 0; it < iters; it++) {
+            if (OP == 11) { REP8(REP8(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));)) }
+            if (OP == 12) { REP8(REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));)) }
+            if (OP == 13) { REP8(REP8(asm volatile("v_add_f64 %0, %0, %5\n v_add_f64 %1, %1, %5\n v_add_f64 %2, %2, %5\n v_add_f64 %3, %3, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));)) }
+        }
+        a0 = (float)(d0 + d1 + d2 + d3);
+    }
+    if (OP == 14) BODY("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4")
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(m & 1);
 }
 
@@ -87,5 +97,7 @@ int main()
     run<3>("v_lshlrev_b32", out, cus, ghz); run<4>("v_bfe_i32", out, cus, ghz); run<5>("v_cvt_f32_i32", out, cus, ghz);
     run<6>("v_cndmask_b32 (sgpr)", out, cus, ghz); run<7>("v_cmp_lt_f32 vcc", out, cus, ghz); run<10>("v_cmp_lt_f32 sgpr", out, cus, ghz);
     run<8>("v_pk_mul_f32", out, cus, ghz); run<9>("v_pk_add_f32", out, cus, ghz);
+    run<11>("v_fma_f64", out, cus, ghz); run<12>("v_mul_f64", out, cus, ghz); run<13>("v_add_f64", out, cus, ghz);
+    run<14>("v_add_u32", out, cus, ghz);
     return 0;
 }

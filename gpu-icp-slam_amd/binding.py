@@ -25,7 +25,7 @@ SYMBOLS = [
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
     "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads",
-    "pfslam_set_serial", "pfslam_debug_check_cells", "pfslam_set_probe", "pfslam_get_probe", "pfslam_probe_name",
+    "pfslam_set_serial", "pfslam_debug_check_cells", "pfslam_set_probe", "pfslam_get_probe", "pfslam_probe_name", "pfslam_frame_mode",
     "pfslam_time_score_grid", "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
 ]
 
@@ -140,6 +140,7 @@ def load():
     L.pfslam_debug_check_cells.argtypes = [vp, vp]
     L.pfslam_set_probe.argtypes = [vp, i32]
     L.pfslam_get_probe.argtypes = [vp, vp, i32, vp, vp]
+    L.pfslam_frame_mode.argtypes = [vp, vp]
     L.pfslam_probe_name.argtypes = [i32]
     L.pfslam_probe_name.restype = C.c_char_p
     L.pfslam_score_grid.argtypes = [vp, vp]
@@ -424,6 +425,11 @@ class PfSlam:
         d = dict(zip(keys, [int(v) for v in out]))
         d["violations"] = sum(v for k, v in d.items() if k.startswith("v_"))
         return d
+
+    def frame_mode(self):
+        out = (C.c_int * 4)()
+        _chk(self.L.pfslam_frame_mode(self._h, out), "pfslam_frame_mode")
+        return {"round5_frame": bool(out[0]), "gates": bool(out[1]), "serial": bool(out[2]), "publish_lag": int(out[3])}
 
     def set_probe(self, frames):
         _chk(self.L.pfslam_set_probe(self._h, int(frames)), "pfslam_set_probe")

@@ -808,6 +808,7 @@ static int dalloc(T **p, size_t count)
 
 static pf::KdView kd_view(const pfslam_handle *h) { return pf::KdView{h->hot, h->kz, h->parent, h->kw, h->planar}; }
 static int settle(pfslam_handle *h);   // finish and book the frames in flight (pfslam_stages.hip.inc)
+static int settle_staged(pfslam_handle *h); // settle + leave the round-5 frame loop (a staged call reads or writes what its frames keep on four streams)
 static int join_all(pfslam_handle *h); // round-5 frames: the tails of the chain / free-cell / cell streams -> the handle's stream
 static void frame_free(pfslam_handle *h);
 static int join_map(pfslam_handle *h); // main stream waits for the map update a frame left on the aux stream
@@ -841,7 +842,8 @@ static int create_impl(pfslam_handle *h)
         HIPCHK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio ? hi : lo));
         static const int kprio = getenv("PFSLAM_K_PRIO") ? atoi(getenv("PFSLAM_K_PRIO")) : 1; // 0 low, 1 normal (default), 2 high
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, kprio == 2 ? hi : kprio == 1 ? (lo + hi) / 2 : lo)); // (beside the scan-match kernel: it must not get in its way)
-        HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, prio ? hi : lo));
+        static const int fprio = getenv("PFSLAM_F_PRIO") ? atoi(getenv("PFSLAM_F_PRIO")) : 2; // A/B: the free cells' stream 0 low, 1 normal, 2 high
+        HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, !prio ? lo : fprio == 2 ? hi : fprio == 1 ? (lo + hi) / 2 : lo));
         HIPCHK(pf_event_create(&h->ev_tree, hipEventDisableTiming));
         HIPCHK(pf_event_create(&h->ev_scored, hipEventDisableTiming));
         h->fstream = h->istream; // round-5 frames: the free cells' chain (their ICP solve rides on the cells' stream)
@@ -1326,7 +1328,7 @@ extern "C" int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_b
 {
     if (!h || !scan_host || n_beams != h->nb) return fail("pfslam_set_scan: n_beams must equal cfg.n_beams");
     HIPCHK(hipSetDevice(h->cfg.device));
-    CHK(settle(h));
+    CHK(settle_staged(h));
     scan_reach_of(h, scan_host);
     HIPCHK(hipMemcpyAsync(h->scan, scan_host, (size_t)n_beams * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream)); // scan_host is pageable: do not return before it is consumed
@@ -1336,7 +1338,7 @@ extern "C" int pfslam_set_scan(pfslam_handle *h, const float *scan_host, int n_b
 extern "C" int pfslam_set_pose(pfslam_handle *h, const float pose[3])
 {
     if (!h || !pose) return fail("pfslam_set_pose: bad argument");
-    CHK(settle(h));
+    CHK(settle_staged(h));
     float p4[4] = {pose[0], pose[1], pose[2], 0.0f};
     memcpy(h->h_pose, pose, 12);
     HIPCHK(hipMemcpyAsync(h->pose, p4, 16, hipMemcpyHostToDevice, h->stream));
@@ -1444,7 +1446,7 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
 {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
-    CHK(settle(h));
+    CHK(settle_staged(h));
     hipLaunchKernelGGL(k_motion, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->w, h->wm,
                        h->n, frame, h->goff);
     HIPCHK(hipGetLastError());
@@ -1566,9 +1568,13 @@ static int plan_min_particles()
     static const int v = getenv("PFSLAM_PLAN_MIN_N") ? atoi(getenv("PFSLAM_PLAN_MIN_N")) : 4608;
     return v;
 }
-static bool org_use_cells(const pfslam_handle *h, bool *use_plan)
+// frame_loop: the round-5 frame of pfslam_step -- nothing on its chain waits for the marking pass or the walks of new cells, so the rows pay
+// from a few waves of particles on (1000 particles: 0.160 -> 0.144 ms per frame, 3000: 0.229 -> 0.177); everywhere else (stage-level calls,
+// the sharded frame: synchronous or same-frame passes) they start at ~4.6 k particles
+static bool org_use_cells(const pfslam_handle *h, bool *use_plan, bool frame_loop = false)
 {
-    const int plan_min_n = plan_min_particles();
+    static const bool env_min = getenv("PFSLAM_PLAN_MIN_N") != nullptr;
+    const int plan_min_n = (frame_loop && !env_min) ? 65 : plan_min_particles();
     const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
     const float Dside = h->n <= 400000 ? 64.0f : 128.0f;
     const float box_cells = 2.0f * (6.4f * h->cloud_sigma / Dside) * cbrtf(64.0f * Dside * Dside * Dside / (float)h->n) / std::min(h->cfg.map_res_x, h->cfg.map_res_y);
@@ -1854,7 +1860,7 @@ extern "C" int pfslam_score_census(pfslam_handle *h, unsigned long long out[8])
 {
     if (!h || !out) return fail("pfslam_score_census: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    CHK(settle(h));
+    CHK(settle_staged(h));
     if (!h->d_census) CHK(dalloc(&h->d_census, 1));
     HIPCHK(hipMemsetAsync(h->d_census, 0, sizeof(pf::KdCensus), h->stream));
     CHK(launch_score(h, false, h->d_census));
@@ -1903,7 +1909,7 @@ extern "C" int pfslam_score_kd(pfslam_handle *h, float *fit_host)
 {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
-    CHK(settle(h));
+    CHK(settle_staged(h));
     CHK(launch_score(h));
     if (fit_host) {
         HIPCHK(hipMemcpyAsync(fit_host, h->fit, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1916,7 +1922,7 @@ extern "C" int pfslam_time_score_kd(pfslam_handle *h, int iters, float *ms_per_l
 {
     if (!h || iters <= 0 || !ms_per_launch) return fail("pfslam_time_score_kd: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    CHK(settle(h));
+    CHK(settle_staged(h));
     CHK(launch_score(h)); // warm
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int k = 0; k < iters; k++) CHK(launch_score(h));
@@ -2160,6 +2166,17 @@ extern "C" int pfslam_get_probe(pfslam_handle *h, unsigned long long *out, int c
         memcpy(out + (size_t)k * PF_PROBE_SLOTS, &all[(size_t)(ticket % h->probe_frames) * PF_PROBE_SLOTS], PF_PROBE_SLOTS * 8);
     }
     *n_frames = n;
+    return 0;
+}
+// how the handle's round-5 frames run: out[0] 1 = the last frame was one, [1] 1 = cross-stream edges are gates (0: events -- asked for, or the
+// start-up self-test found two streams on one hardware queue), [2] one-stream mode, [3] publication lag in frames
+extern "C" int pfslam_frame_mode(pfslam_handle *h, int out[4])
+{
+    if (!h || !out) return fail("pfslam_frame_mode: bad argument");
+    out[0] = h->pipe_live ? 1 : 0;
+    out[1] = h->gates;
+    out[2] = h->serial;
+    out[3] = h->publish_lag;
     return 0;
 }
 extern "C" const char *pfslam_probe_name(int slot) { return slot >= 0 && slot < PB_END ? pb_names[slot] : ""; }

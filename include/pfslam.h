@@ -311,6 +311,8 @@ int pfslam_debug_check_cells(pfslam_handle *h, long long out[16]);
 int pfslam_set_probe(pfslam_handle *h, int frames);
 int pfslam_get_probe(pfslam_handle *h, unsigned long long *out, int cap_frames, int *n_frames, int *last_ticket);
 const char *pfslam_probe_name(int slot);
+/* out[0] 1 = the last frame ran as a round-5 frame, [1] 1 = its cross-stream edges are gates (0 = events), [2] 1 = one-stream mode, [3] publication lag */
+int pfslam_frame_mode(pfslam_handle *h, int out[4]);
 
 /* ---- host-side map structure (kdtree.cpp counterpart; no GPU needed) ---- */
 int pfslam_kd_create(const float *pts_xyzw, int n, pfslam_node *out);

@@ -55,8 +55,8 @@ def _torchrun(nproc, port, *bench_args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3",
            "--warmup", "1", "--particles", "4096", "--map-points", "20000"] + list(bench_args)
-    # (the process-group bootstrap has been seen to hang on some leases -- 2 of 6 boxes in round 5, never reproducible on the same box
-    # twice, with and without this round's changes --: a watchdog inside bench.py, a bounded wait here, and one retry on a fresh port)
+    # (the process-group bootstrap has been seen to hang on some leases -- 2 of 8 boxes in round 5, never
+    # reproducible in a loop of the same command on another box --: a watchdog inside bench.py, a bounded wait here, and one retry on a fresh port)
     out = None
     for attempt in range(2):
         cmd[cmd.index("--master-port") + 1] = str(port + 20 * attempt)

@@ -64,6 +64,7 @@ def main():
     print("scan-match kernel (start to reduce start, incl. its launch gap): mean %.1f us" % (t[:, rd] - t[:, sc])[ok].mean())
     print("cell stats:", {k: v for k, v in e.cell_stats().items() if k in ("cells", "rows", "pool_slots", "walked_from_root", "extended", "updates", "wipes", "flags")})
     print("cell check:", e.check_cells())
+    print("frame mode:", e.frame_mode())
     e.close()
 
 

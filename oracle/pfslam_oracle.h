@@ -15,11 +15,21 @@
  *     thrust itself is a dependency absent from /root/reference (CUDA 7.5 toolkit).
  *   - 3x3 SVD (svd3.h): PINNED on the GPU box against the reference's own svd3.h compiled unmodified for
  *     the device (oracle/svd_ref_kernel.cpp -> oracle/_ref/svd_ref.hsaco); tests/test_gpu_svd_ref.py.
- *   - Everything that only the CUDA device could execute (traversal, scoring,
- *     ICP kernels, map update, resample): PARITY UNPINNED -- the reference has no
- *     tests / golden vectors and cannot be built or run here (nvcc, libmat, PCL,
- *     GL all absent).  The restatement follows the cited lines literally; the
- *     undefined behaviours H1..H11 are given the definitions in DESIGN.md.
+ *   - The device kernels of kernel.cu (traversal: findCorrespondenceIndexKD / findCorrespondenceKD / the loop inside
+ *     EvaluateParticleKD; kernEvaluateParticlesKD as a whole; traceRay / kernGetWalls / kernGetWallsKD; getHyperplaneDist;
+ *     utilhash / makeSeededRandomEngine / uniform_real; kernWeightedSample; kernAddNoise; kernUpdateWeights /
+ *     kernCopyWeights; kernUpdateMapKD / kernTestCorrespondance; kernEvaluateParticles / kernUpdateMap): PINNED on the GPU
+ *     box against the reference's own kernel.cu compiled for gfx950, device code only, from a scratch copy made at build
+ *     time by sed (byte-order mark; the blank inside `<< <` / `>> >`) and hipify-perl -- no hand edit, nothing committed
+ *     (oracle/kernel_ref_wrap.cpp, oracle/Makefile -> oracle/_ref/kernel_ref.hsaco; tests/test_gpu_ref_kernels.py).
+ *     Bit for bit wherever no transcendental function is involved, and bit for bit BEHIND CleanLidarScan's cos / sin (the
+ *     reference's own end points fed to the restated traversal / ray code).  BOUND of that pin: the transcendentals of that
+ *     build are ROCm's device library, not CUDA's libdevice (the fp64 specification here agrees with ROCm's cosf / sinf on
+ *     70 % of the end points, always within 2 ulp; scores change only at nearest-node ties: 7 of 12 000 particles of the
+ *     bench workload), and nvcc's default fma contraction is a property of ITS code generation (the same text built with
+ *     clang's contraction on is reported beside it).  What never ran anywhere here: the reference's HOST code of
+ *     kernel.cu (thrust reductions' order, the cudaMemcpy choreography, PFUpdateMapKD's host loops) -- restated from the
+ *     cited lines; the undefined behaviours H1..H11 are given the definitions in DESIGN.md.
  *
  * Arithmetic contract: IEEE-754 binary32, one rounding per source-level
  * operation, no FMA contraction (built with -ffp-contract=off), sqrt and divide

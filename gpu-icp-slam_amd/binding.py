@@ -24,7 +24,7 @@ SYMBOLS = [
     "pfslam_score_grid", "pfslam_update_map_grid", "pfslam_traverse", "pfslam_measurement_local",
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
-    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads",
+    "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads", "pfslam_kd_whole_node",
     "pfslam_set_serial", "pfslam_debug_check_cells", "pfslam_set_probe", "pfslam_get_probe", "pfslam_probe_name", "pfslam_frame_mode",
     "pfslam_time_score_grid", "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
 ]

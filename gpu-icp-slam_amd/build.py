@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libpfslam_hip.so")
 INC = os.path.join("..", "..", "include", "pfslam.h")
 # source -> extra dependencies
 UNITS = {
-    "pfslam_hip.hip": ["pf_math.h", "kd_device.h", "kd_cells.hip.inc", "pfslam_stages.hip.inc", INC],
+    "pfslam_hip.hip": ["pf_math.h", "kd_device.h", "kd_cells.hip.inc", "pfslam_stages.hip.inc", "pfslam_frame.hip.inc", INC],
     "kd_host.cpp": [INC],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",

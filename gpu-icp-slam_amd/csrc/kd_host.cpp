@@ -62,8 +62,16 @@ int usable_cores()
 #endif
     return std::max(n, 1);
 }
+// The one-build-per-node protocol (pfslam_shard_balance_build: rank 0 builds while every other rank of the node waits in the broadcast)
+// lifts the split by LOCAL_WORLD_SIZE for the length of that build: pfslam_kd_whole_node(1) ... (0).
+static std::atomic<int> g_whole_node{0};
+extern "C" void pfslam_kd_whole_node(int on) { g_whole_node.store(on ? 1 : 0); }
 int sort_thread_budget()
 {
+    if (g_whole_node.load() && !getenv("PFSLAM_SORT_THREADS")) {
+        static const int whole = std::max(1, std::min(usable_cores(), 64));
+        return whole;
+    }
     static const int n = [] {
         if (const char *e = getenv("PFSLAM_SORT_THREADS")) return std::max(1, atoi(e));
         int ranks = 1;

@@ -1555,7 +1555,9 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
     const int recut = recut_every > 0 && h->cells_passes > 0 && h->cells_passes % recut_every == 0 ? 1 : 0;
     if (recut) HIPCHK(hipMemsetAsync(h->cell_state + PF_CS_POOL, 0, 4, st));
     hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,
-                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15), recut, h->cells_snap ? 1 : 0);
+                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15), recut, 1);
+    // (always below the snapshot: the walk pass of an asynchronous frame or the synchronous publishing pass of launch_score left it -- after a
+    // synchronous pass the next frame's marking pass may already be bumping the counter in front of list entries it has not written yet)
     h->cells_snap = false;
     HIPCHK(hipGetLastError());
     h->cells_passes++;
@@ -1630,6 +1632,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     if (use_cells && !h->cell_tab) {
         CHK(dalloc(&h->cell_tab, (size_t)PF_CELL_WIN * PF_CELL_WIN));
         CHK(dalloc(&h->cell_list, (size_t)PF_CELL_LIST_CAP));
+        HIPCHK(hipMemsetAsync(h->cell_list, 0, (size_t)PF_CELL_LIST_CAP * 4, h->stream));
         CHK(dalloc(&h->cell_state, PF_CS_ALLOC)); // ([64, 128): PF_CELLS_PROFILE builds)
         HIPCHK(hipMemsetAsync(h->cell_state, 0, PF_CS_ALLOC * 4, h->stream));
         CHK(dalloc(&h->cell_rec, (size_t)PF_CELL_LIST_CAP * PF_REC_WORDS));
@@ -1794,7 +1797,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (use_cells) { // rows of the new cells (and a look at every record's links)
             if (cells_sync) h->cells_passes++;
             if (cells_sync)
-                hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, h->stream, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0);
+                hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, h->stream, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0, 0, 2);
         } else
             hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                                (const float *)h->scan, h->nb, kd_view(h), h->plan);

@@ -325,6 +325,9 @@ int pfslam_kd_balance(pfslam_node *list, int n);
 int pfslam_kd_parallel_sort(void);
 /* threads a host-side build may use: usable cores (scheduler affinity, cgroup quota) / LOCAL_WORLD_SIZE; PFSLAM_SORT_THREADS overrides */
 int pfslam_kd_sort_threads(void);
+/* 1: lift the LOCAL_WORLD_SIZE split (the caller is the node's only builder while the other ranks wait: pfslam_shard_balance_build
+ * does this around its build), 0: back to the per-rank share.  No reference counterpart (the reference is single-process). */
+void pfslam_kd_whole_node(int on);
 
 #ifdef __cplusplus
 }

@@ -40,3 +40,17 @@ def test_struct_layouts_match_reference(pkg):
     assert pkg.PARTICLE_DTYPE.fields["cluster"][1] == 16
     assert pkg.PARTICLE_DTYPE.fields["map"][1] == 24
     assert ctypes.sizeof(pkg.Config) == 64
+
+
+def test_whole_node_thread_budget():
+    """One KDTree::Balance per node (rank 0 builds, the others wait in the broadcast): the build may use every usable core, not the
+    rank's 1 / LOCAL_WORLD_SIZE share (pfslam_kd_whole_node, set by pfslam_shard_balance_build around its build)."""
+    import subprocess, sys, os
+    code = ("import importlib, sys; sys.path.insert(0, %r); pkg = importlib.import_module('gpu-icp-slam_amd'); L = pkg.load();"
+            "a = L.pfslam_kd_sort_threads(); L.pfslam_kd_whole_node(1); b = L.pfslam_kd_sort_threads(); L.pfslam_kd_whole_node(0);"
+            "c = L.pfslam_kd_sort_threads(); print(a, b, c)" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, LOCAL_WORLD_SIZE="8")
+    env.pop("PFSLAM_SORT_THREADS", None)
+    a, b, c = map(int, subprocess.check_output([sys.executable, "-c", code], env=env).split()[-3:])
+    one = int(subprocess.check_output([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="1")).split()[-3])
+    assert a == c == max(1, min(one, 64) // 8 if one >= 8 else 1) and b == one

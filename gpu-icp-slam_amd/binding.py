@@ -74,9 +74,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("PFSLAM_LIB") or _build.LIB  # (PFSLAM_LIB: an A/B build of the same sources, tools/experiments)
     try:
-        if _build.stale():
+        if path == _build.LIB and _build.stale():
             _build.build()
     except Exception as e:  # a prebuilt .so that travelled with the snapshot is still usable
         if not os.path.exists(path):

@@ -238,6 +238,7 @@ struct pfslam_handle {
     hipStream_t cstream = nullptr;  // marking + walks of the new cells in the frame loops: beside the ICP solve, under the scan-match kernel
     hipEvent_t ev_walked = nullptr; // ... finished: the frame's insert (k_test_new changes the tree they read) waits for it
     bool walk_pending = false;
+    bool update_unsnapped = false; // the last post-insert k_cells_update read the raw list counter: the next marking pass starts behind it
     bool cells_snap = false;       // this frame's k_cells_update<true> may run beside the next frame's marking pass: records below the walk pass's snapshot only
     pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
@@ -1555,9 +1556,12 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
     const int recut = recut_every > 0 && h->cells_passes > 0 && h->cells_passes % recut_every == 0 ? 1 : 0;
     if (recut) HIPCHK(hipMemsetAsync(h->cell_state + PF_CS_POOL, 0, 4, st));
     hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,
-                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15), recut, 1);
-    // (always below the snapshot: the walk pass of an asynchronous frame or the synchronous publishing pass of launch_score left it -- after a
-    // synchronous pass the next frame's marking pass may already be bumping the counter in front of list entries it has not written yet)
+                       h->cell_pool, h->cell_rec, h->cells_gen, (const int *)h->cell_touched, (int)(h->cells_passes & 15), recut, h->cells_snap ? 1 : 0);
+    // Below the snapshot whenever this frame's scoring pass left one (the walk pass of an asynchronous frame, the publishing pass of a
+    // synchronous one: the next frame's marking pass may already be bumping the counter in front of list entries it has not written yet).
+    // A frame scored WITHOUT a cell pass (the plan, the plain traversal) has none -- the last one may be frames old, or wiped: every record
+    // is looked at, and the next marking pass waits for this update instead (launch_score).
+    h->update_unsnapped = !h->cells_snap;
     h->cells_snap = false;
     HIPCHK(hipGetLastError());
     h->cells_passes++;
@@ -1717,6 +1721,10 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             HIPCHK(hipStreamWaitEvent(h->cstream, h->ev_boxes, 0));
             st = h->cstream;
         }
+        if (h->update_unsnapped) { // (see launch_cells_update; an event that has fired -- or was never recorded -- costs nothing)
+            HIPCHK(hipStreamWaitEvent(st, h->ev_map, 0));
+            h->update_unsnapped = false;
+        }
         const int groups = (h->n + 63) / 64, per_block = PF_MARK_THREADS * PF_MARK_GROUPS;
         hipLaunchKernelGGL(k_cells_mark, dim3(h->nb, (groups + per_block - 1) / per_block), dim3(PF_MARK_THREADS), 0, st,
                            (const pf::KdGroupBox *)h->group_box, groups, (const float *)h->scan, h->nb, geo, h->cell_tab, h->cell_list, h->cell_state,
@@ -1798,6 +1806,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             if (cells_sync) h->cells_passes++;
             if (cells_sync)
                 hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, h->stream, kd_view(h), geo, ca.tab, (const int *)ca.list, ca.cs, ca.pool, ca.rec, h->cells_gen, (const int *)nullptr, 0, 0, 2);
+            if (cells_sync) h->cells_snap = true; // (use_snap 2: the pass has left the snapshot)
         } else
             hipLaunchKernelGGL(k_plan, dim3((groups + 63) / 64, h->nb), dim3(64), 0, h->stream, (const pf::KdGroupBox *)h->group_box, groups,
                                (const float *)h->scan, h->nb, kd_view(h), h->plan);
@@ -2029,6 +2038,9 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
         HIPCHK(hipMemcpy(prof, h->cell_state + 64, sizeof(prof), hipMemcpyDeviceToHost));
         int waves = 0;
         HIPCHK(hipMemcpy(&waves, h->cell_state + 63, 4, hipMemcpyDeviceToHost));
+        int ext[2];
+        HIPCHK(hipMemcpy(ext, h->cell_state + 60, 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "extensions %d, of them without a new candidate or re-descent candidate %d\n", ext[0], ext[1]);
         fprintf(stderr, "k_cells_update<true> phases over %d wave-passes (mean / max us):", waves);
         for (int p = 0; p < 9; p++) fprintf(stderr, "  [%d] %.2f / %.2f", p, waves ? prof[2 * p] * 0.01 / waves : 0.0, prof[2 * p + 1] * 0.01);
         fprintf(stderr, "\n  slowest wave of the last 16 passes (us) / waves above 20 us:");
@@ -2052,7 +2064,8 @@ extern "C" int pfslam_cell_stats(pfslam_handle *h, double out[16])
 //   * a claimed cell that is not published yet (never walked, or walked and FRESH) still has its claim word PENDING;
 //   * the table holds exactly the rows / fallback words the counters say, and one PENDING word per unpublished record.
 // out: [0] records  [1] never walked  [2] fresh  [3] published  [4] row words in the table  [5] pending words  [6] fallback words
-//      [7] dead records  [8..15] violations: unwalked-not-pending, fresh-not-pending, row outside its allocation, row slot not a candidate
+//      [7] dead records  [8..15] violations: unwalked-not-pending, fresh-not-pending, row outside its allocation (or a table word that is not the one
+//      the record published last), row slot not a candidate
 //      (or out of order), watched link has a child, malformed link word, dead record with a row, counter mismatch (host side)
 __global__ __launch_bounds__(256) void k_cells_check(pf::KdView tree, const unsigned *__restrict__ tab, const int *__restrict__ list, const int *__restrict__ cs,
                                                      const uint4 *__restrict__ pool, const int *__restrict__ rec_base, int gen, unsigned long long *__restrict__ out)
@@ -2070,12 +2083,13 @@ __global__ __launch_bounds__(256) void k_cells_check(pf::KdView tree, const unsi
         const unsigned wd[4] = {w0, tab[cell + 1], tab[cell + PF_CELL_WIN], tab[cell + PF_CELL_WIN + 1]};
         if (fl & PF_RF_DEAD) {
             c[7]++;
-            for (int b = 0; b < 4; b++) if (wd[b] != PF_CELL_FALLBACK) c[14]++;
+            for (int b = 0; b < 4; b++) if (wd[b] != PF_CELL_FALLBACK || (unsigned)rec[PF_REC_LAST + b] != wd[b]) c[14]++;
             continue;
         }
         c[3]++;
         const int p0 = rec[PF_REC_POOL], plen = rec[PF_REC_POOL + 1];
         for (int b = 0; b < 4; b++) {
+            if ((unsigned)rec[PF_REC_LAST + b] != wd[b]) { c[10]++; continue; } // the table word is not what the record says it published last (its accounts would close wrongly)
             if (wd[b] == PF_CELL_FALLBACK) continue;
             if (wd[b] == 0u || wd[b] >= 0x40000000u) { c[9]++; continue; }
             const int n1 = (int)(wd[b] & 15u), n2 = (int)((wd[b] >> 4) & 15u), off = (int)(wd[b] >> 8);

@@ -253,6 +253,9 @@ struct pfslam_handle {
     float2 *wall_xy2 = nullptr;   // k_walls<1> -> k_walls_traverse -> k_walls<3>: the frame's wall points, the link each falls off, new-wall flags
     int *wall_leaf2 = nullptr, *wall_new2 = nullptr;
     int *wall_c2 = nullptr;       // nearest index of every wall of the frame (k_walls -> k_wall_weights)
+    uint32_t *wall_runs = nullptr, *wall_keys_s = nullptr; // k_wall_runs -> k_walls_rank_traverse -> k_walls<3>: the beams' wall cells sorted inside runs of 64; in
+    double2 *tparts = nullptr, *tparts_cur = nullptr; // cos / sin of every particle's heading as doubles (k_motion_count -> the frame's scan-match kernel)
+    int *wall_c2s = nullptr;      // rank order with the duplicates flagged (the other per-wall arrays of that chain are indexed by rank too)
     long long *fstats = nullptr;  // packed min / max keys, [2][4] by ticket parity (a frame's last reduce workgroup resets the other one)
     float *cloud = nullptr;       // cloud statistics {mean x, y, heading, spread}, [2][4] by ticket parity
     float *sigr = nullptr;        // [PF_FRAME_RING][80]: {spread, -, 64 partial maxima of |heading|} of a frame's cloud -> header part A

@@ -271,6 +271,7 @@ struct pfslam_handle {
     int *order_tmp = nullptr;
     int mark_early = 1;           // the cells' passes start with the lane order (0: behind the frame's reduce)
     int gates = 1;                // cross-stream edges of a round-5 frame through device words + one-wave gate kernels instead of events (k_gate)
+    bool ftail_recorded = false;  // ev_ftail holds the tail of the last frame's free-cell chain (not with the FTAIL gate: recorded by whoever needs it)
     int *flags = nullptr;         // PF_FL_*: the ticket of the last frame whose reduce / insert / lane order / ICP solve is done
     int *gate_err = nullptr, *gate_err_dev = nullptr; // pinned: ticket of a frame one of whose gates gave up (reported by the call that books it)
     const float *x_frame = nullptr, *y_frame = nullptr, *th_frame = nullptr;
@@ -1482,6 +1483,10 @@ extern "C" int pfslam_shift_particles(pfslam_handle *h, const float delta[3])
     if (h->pipe_live && !h->serial) { // round-5 frames: the pose's readers of the last frame are k_walls (chain) and the free-cell chain
         HIPCHK(hipEventRecord(h->ev_tail[0], h->aux));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tail[0], 0));
+        if (!h->ftail_recorded) { // (stream gates: the free-cell chain's tail is not recorded per frame)
+            HIPCHK(hipEventRecord(h->ev_ftail, h->fstream));
+            h->ftail_recorded = true;
+        }
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ftail, 0));
     }
     const float ad = delta[2] == delta[2] ? fabsf(delta[2]) : INFINITY;

@@ -1511,7 +1511,11 @@ static int score_chunks(const pfslam_handle *h)
     const int groups = (h->n + 63) / 64;
     // (round 5: 65 536 -- 42 chunks of 26 beams at 100 k particles.  A wave's prologue, the fp64 sincos of its 64 headings, is ~10 % of a
     // 13-beam chunk, and the reduce reads half the partials: frame 0.530 -> 0.520 ms in an A/B on one box; 32 768: 0.538, 262 144: 0.569)
-    static const int target = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 65536;
+    // Below ~40 k particles fewer, longer waves win (a wave's prologue and the launch's ramp against the beams it scores): ~160 chunks per
+    // group between 24 576 and 65 536 waves (profiles/r05_sweep_waves.txt: 10 k particles 0.218 -> 0.209 ms per frame, 20 k 0.2493 -> 0.2478,
+    // 1 k / 4 k unchanged within noise)
+    static const int target_env = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 0;
+    const int target = target_env > 0 ? target_env : std::max(24576, std::min(65536, groups * 160));
     int chunks = (target + groups - 1) / groups;
     chunks = std::max(1, std::min(chunks, h->nb)); // small particle counts go down to one beam per wave
     // Beam-chunk partials added afterwards equal the reference's sequential beam-order float sum only when every term is an

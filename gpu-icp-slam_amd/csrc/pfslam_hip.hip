@@ -1851,7 +1851,9 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
                            h->fit, (long long *)h->stats);
         HIPCHK(hipGetLastError());
     } else if (used > 1 && fuse_minmax) {
-        hipLaunchKernelGGL(k_reduce_partials_minmax, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
+#define PF_REDUCE4_WGS 128 /* workgroups of k_reduce_partials_minmax (grid-stride over the slots; see the kernel) */
+        static const int reduce4_wgs = getenv("PFSLAM_REDUCE4_WGS") ? std::max(1, atoi(getenv("PFSLAM_REDUCE4_WGS"))) : PF_REDUCE4_WGS; // (A/B: 1000000 = one workgroup per 256 slots)
+        hipLaunchKernelGGL(k_reduce_partials_minmax, dim3(std::min((h->n + 255) / 256, reduce4_wgs)), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
                            acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th,
                            shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0, p16 ? 1 : 0);
         HIPCHK(hipGetLastError());

@@ -1564,7 +1564,7 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
     // move to the pool's end, and after ~20 frames the rows a wave gathers together no longer sit together -- the scan-match kernel,
     // with nothing running beside it, went from 0.37 to 0.40-0.42 ms between the 10th and the 20th frame after a wipe (the round-3
     // build, which cut everything every frame, stayed flat).  A cut needs no walk: the records hold the candidates.
-    static const int recut_every = getenv("PFSLAM_CELLS_RECUT_EVERY") ? atoi(getenv("PFSLAM_CELLS_RECUT_EVERY")) : 8;
+    static const int recut_every = getenv("PFSLAM_CELLS_RECUT_EVERY") ? atoi(getenv("PFSLAM_CELLS_RECUT_EVERY")) : 16; // (as in the round-5 frame: tools/experiments/r05/recut_ab.sh)
     const int recut = recut_every > 0 && h->cells_passes > 0 && h->cells_passes % recut_every == 0 ? 1 : 0;
     if (recut) HIPCHK(hipMemsetAsync(h->cell_state + PF_CS_POOL, 0, 4, st));
     hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,

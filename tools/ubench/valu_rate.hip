@@ -64,6 +64,25 @@ __global__ __launch_bounds__(256) void k_valu(int iters, float *out)
         a0 = (float)(d0 + d1 + d2 + d3);
     }
     if (OP == 14) BODY("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4")
+    // round 5, second table: which of the other instructions of the scan-match kernel's loop belong to the 2.4-cycle class
+#define ONE2(OPN, I) if (OP == OPN) BODY(I " %0, %0, %4\n " I " %1, %1, %4\n " I " %2, %2, %4\n " I " %3, %3, %4")
+#define ONE1(OPN, I) if (OP == OPN) BODY(I " %0, %0\n " I " %1, %1\n " I " %2, %2\n " I " %3, %3")
+    ONE1(15, "v_mov_b32") ONE2(16, "v_min_f32") ONE2(17, "v_max_f32") ONE2(18, "v_and_b32") ONE2(19, "v_or_b32") ONE2(20, "v_sub_f32")
+    ONE2(21, "v_sub_u32") ONE2(28, "v_xor_b32") ONE2(29, "v_lshrrev_b32") ONE2(30, "v_subrev_u32") ONE2(31, "v_mul_u32_u24") ONE2(32, "v_min_u32")
+    ONE1(23, "v_cvt_flr_i32_f32") ONE1(24, "v_fract_f32") ONE1(33, "v_floor_f32") ONE1(34, "v_cvt_i32_f32") ONE1(35, "v_rcp_f32") ONE1(36, "v_sqrt_f32")
+    if (OP == 22) BODY("v_mad_u32_u24 %0, %0, %4, %5\n v_mad_u32_u24 %1, %1, %4, %5\n v_mad_u32_u24 %2, %2, %4, %5\n v_mad_u32_u24 %3, %3, %4, %5")
+    if (OP == 25) BODY("v_lshl_or_b32 %0, %0, 1, %4\n v_lshl_or_b32 %1, %1, 1, %4\n v_lshl_or_b32 %2, %2, 1, %4\n v_lshl_or_b32 %3, %3, 1, %4")
+    if (OP == 37) BODY("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5")
+    if (OP == 38) BODY("v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %4, %5\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %4, %5")
+    if (OP == 39) BODY("v_med3_f32 %0, %0, %4, %5\n v_med3_f32 %1, %1, %4, %5\n v_med3_f32 %2, %2, %4, %5\n v_med3_f32 %3, %3, %4, %5")
+    if (OP == 40) BODY("v_bfi_b32 %0, %0, %4, %5\n v_bfi_b32 %1, %1, %4, %5\n v_bfi_b32 %2, %2, %4, %5\n v_bfi_b32 %3, %3, %4, %5")
+    if (OP == 41) BODY("v_and_or_b32 %0, %0, %4, %5\n v_and_or_b32 %1, %1, %4, %5\n v_and_or_b32 %2, %2, %4, %5\n v_and_or_b32 %3, %3, %4, %5")
+    if (OP == 42) {
+        for (int it = 0; it < iters; it++) { // select on vcc (the compiler's usual form)
+            REP8(REP8(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");))
+        }
+    }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(m & 1);
 }
 
@@ -99,5 +118,13 @@ int main()
     run<8>("v_pk_mul_f32", out, cus, ghz); run<9>("v_pk_add_f32", out, cus, ghz);
     run<11>("v_fma_f64", out, cus, ghz); run<12>("v_mul_f64", out, cus, ghz); run<13>("v_add_f64", out, cus, ghz);
     run<14>("v_add_u32", out, cus, ghz);
+    run<15>("v_mov_b32", out, cus, ghz); run<16>("v_min_f32", out, cus, ghz); run<17>("v_max_f32", out, cus, ghz); run<20>("v_sub_f32", out, cus, ghz);
+    run<37>("v_fmac_f32", out, cus, ghz); run<39>("v_med3_f32", out, cus, ghz);
+    run<18>("v_and_b32", out, cus, ghz); run<19>("v_or_b32", out, cus, ghz); run<28>("v_xor_b32", out, cus, ghz); run<29>("v_lshrrev_b32", out, cus, ghz);
+    run<21>("v_sub_u32", out, cus, ghz); run<30>("v_subrev_u32", out, cus, ghz); run<32>("v_min_u32", out, cus, ghz); run<31>("v_mul_u32_u24", out, cus, ghz);
+    run<22>("v_mad_u32_u24", out, cus, ghz); run<25>("v_lshl_or_b32", out, cus, ghz); run<38>("v_add3_u32", out, cus, ghz); run<40>("v_bfi_b32", out, cus, ghz);
+    run<41>("v_and_or_b32", out, cus, ghz); run<42>("v_cndmask_b32 (vcc)", out, cus, ghz);
+    run<23>("v_cvt_flr_i32_f32", out, cus, ghz); run<24>("v_fract_f32", out, cus, ghz); run<33>("v_floor_f32", out, cus, ghz); run<34>("v_cvt_i32_f32", out, cus, ghz);
+    run<35>("v_rcp_f32", out, cus, ghz); run<36>("v_sqrt_f32", out, cus, ghz);
     return 0;
 }

@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--cloud-sigma", type=float, default=0.0, help="start from a Gaussian cloud of this spread (m; heading: sigma / 8 rad) instead of the dispersed start cloud")
     ap.add_argument("--topology", type=int, default=0, help="1 | 2: UpdateTopology + CheckLoopClosure inside the frame (kernel.cu:1750-1751; BASELINE configs[4]); "
                     "the line then carries the graph size and the loop-closure proposals of the last timed frame")
+    ap.add_argument("--collectives", default="rccl", choices=["rccl", "torch"],
+                    help="who issues the frame's all-gathers: rccl = libpfslam_mgpu.so launches them straight into the frame's own streams (default); "
+                         "torch = torch.distributed with the frame's stream as the current stream (debugging; what --backend gloo / --same-device use)")
     ap.add_argument("--dry-collectives", action="store_true", help="also time the frame's collectives on their own (per-rank wall times in the line); with one rank: the fields, no traffic")
     return ap.parse_args()
 
@@ -337,7 +340,7 @@ def main():
     tree = pkg.kd_create(pts)
     long_run = not a.no_cpu_baseline
     # long-run leg: filler up to the next frame % 100 == 6, 100 timed frames, 20 frames for the phase split
-    n_frames = a.warmup + 2 * a.steps + (((6 - (FIRST_FRAME + a.warmup + a.steps)) % 100) + 100 + 20 if long_run else 0)   # (+ steps: the frame-probe leg)
+    n_frames = a.warmup + 3 * a.steps + (100 + 100 + 20 if long_run else 0)   # (+ 2 x steps: the frame-probe leg and the steady-state window; long run: filler up to the next frame % 100 == 6, then 100 + 20)
 
     def one_scan(f):
         return pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f)
@@ -347,11 +350,19 @@ def main():
 
     cap = a.map_points + (1 << 18)
 
+    native = distributed and a.collectives == "rccl" and a.backend == "nccl" and not a.same_device
+
     def make_engine():
         if distributed:
             from importlib import import_module
             sharded = import_module("gpu-icp-slam_amd.sharded")
-            e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch)
+            job_id = None
+            if native and world > 1:   # rank 0 makes the job's RCCL id (two communicators: particle stream, chain stream); the process group carries it
+                box = [pkg.mgpu_make_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                job_id = box[0]
+            e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch,
+                                    native=native, native_id=job_id)
         else:
             e = pkg.PfSlam(n_local, kd_capacity=cap, device=local_rank)
         e.set_map(tree)
@@ -377,7 +388,10 @@ def main():
 
     def barrier():
         eng.synchronize()
-        if dist is not None:
+        if getattr(eng, "native", None) is not None:
+            eng.native.barrier_max()     # device synchronisation + an all-reduce on the job's own RCCL communicator (a process-group barrier costs ~1 ms: 10 % of a 20-step window)
+            torch.cuda.synchronize()
+        elif dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -403,27 +417,31 @@ def main():
         """The frame's collectives on their own, same buffers and sizes as the frame issues them, `reps` each, bracketed by events on
         the stream the frame runs on (ms per call, this rank).  One rank: the sizes only -- nothing moves."""
         sizes = {"pose_blocks_bytes_per_rank": 3 * eng.stride * 4 if hasattr(eng, "stride") else 3 * n_local * 4,
-                 "records_bytes_per_rank": 32, "weights_bytes_per_rank": (eng.stride if hasattr(eng, "stride") else n_local) * 4,
+                 "records_bytes_per_rank": 16, "weights_bytes_per_rank": (eng.stride if hasattr(eng, "stride") else n_local) * 4,
                  "balance_broadcast_bytes": 28 * int(e0.kd_size) + 16}
-        res = {"sizes": sizes, "world": world, "ms": None,
-               "note": "pose blocks and weights are gathered on the collective's own stream under the scan-match kernel / the map update; "
-                       "the 32-byte records sit on the frame's critical chain; the broadcast happens once per KDTree::Balance (100 frames)"}
+        res = {"sizes": sizes, "world": world, "ms": None, "issued_by": "libpfslam_mgpu.so (ncclAllGather into the frame's own streams)" if native else "torch.distributed",
+               "note": "pose blocks: on the particle stream, under the scan-match kernel; the 16-byte records (a shard's packed keys): on the chain "
+                       "stream between the reduce and the walls -- the one collective on the frame's critical chain; weights: on the particle stream; "
+                       "the broadcast happens once per KDTree::Balance (100 frames).  ms = each collective on its own, back to back, per call"}
         if dist is None or world == 1:
             return res
-        b = eng.buf
-        local, glob = b.pose_blocks()
-        ops = {"pose_blocks": lambda: dist.all_gather_into_tensor(glob, local),
-               "records": lambda: dist.all_gather_into_tensor(b.packs, b.pack),
-               "weights": lambda: dist.all_gather_into_tensor(b.gw, b.w)}
-        ms = {}
-        for name, op in ops.items():
-            op(); torch.cuda.synchronize(); dist.barrier()
-            e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e_a.record()
-            for _ in range(reps):
-                op()
-            e_b.record(); torch.cuda.synchronize()
-            ms[name] = e_a.elapsed_time(e_b) / reps
+        if getattr(eng, "native", None) is not None:
+            ms = eng.native.time_collectives(reps)
+        else:
+            b = eng.buf
+            local, glob = b.pose_blocks()
+            ops = {"pose_blocks": lambda: dist.all_gather_into_tensor(glob, local),
+                   "records": lambda: dist.all_gather_into_tensor(b.packs, b.pack),
+                   "weights": lambda: dist.all_gather_into_tensor(b.gw, b.w)}
+            ms = {}
+            for name, op in ops.items():
+                op(); torch.cuda.synchronize(); dist.barrier()
+                e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e_a.record()
+                for _ in range(reps):
+                    op()
+                e_b.record(); torch.cuda.synchronize()
+                ms[name] = e_a.elapsed_time(e_b) / reps
         t = torch.tensor([ms[k] for k in sorted(ms)], dtype=torch.float64, device="cuda")
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
@@ -441,6 +459,11 @@ def main():
     eng.set_timing(0)
     trace = eng.trace()
     pose_timed = np.array(eng.pose, np.float32)
+    # how the timed frames ran: the round-5 frame (four in-order streams), its cross-stream edges as device-word gates or as events (the
+    # start-up self-test decides; a second handle in the process withdraws the gates), one-stream mode
+    fm = e0.frame_mode()
+    frame_mode_timed = {"round5_frame": fm["round5_frame"], "edges": "gates" if fm["gates"] else "events", "one_stream": fm["serial"],
+                        "sharded_frame": bool(distributed), "collectives": ("rccl, launched into the frame's own streams" if native else "torch.distributed") if world > 1 else None}
     topo_info = None
     if a.topology:   # replicated state: every rank holds the same graph and proposes the same pairs
         nodes_t, idx_t = eng.topology()
@@ -472,6 +495,16 @@ def main():
                                            "threads over the %d frames BEHIND the timed window, same handle" % a.steps}
         except Exception as e:  # the probe must never break the contract line
             frame_probe = {"error": repr(e)}
+    # ---- steady state: the same K steps once more, further into the run (every rank takes part).  The contract window above starts right
+    # behind the warm-up, while the synthetic start cloud is still settling (the run's most expensive stretch); this one is the rate the
+    # loop runs at from then on.  Reported beside `value`, never in its place.
+    steady = None
+    k_steady = a.warmup + a.steps + probe_frames
+    if k_steady + a.steps <= n_frames:
+        dts = timed(k_steady, a.steps, frame)
+        steady = {"value": n_global * a.steps / dts, "ms_per_step": dts / a.steps * 1e3, "frames": "%d..%d" % (frame, frame + a.steps - 1), "unit": "particle-scan evals/s"}
+        frame += a.steps
+        probe_frames += a.steps   # (the long-run leg goes on behind these frames)
 
     # ---- census replay: what exactly did the timed launches issue?  A second handle steps through the same frames -- the frame
     # loop is deterministic, so its particles, scans and map are the timed run's, bit for bit (checked on the pose) -- with the
@@ -506,6 +539,9 @@ def main():
         }
         if topo_info is not None:
             out["config"]["topology"] = topo_info
+        out["config"]["frame_mode"] = frame_mode_timed
+        if steady is not None:
+            out["steady_state"] = steady
         if frame_probe is not None:
             out["frame"] = frame_probe
         if per_rank_s:

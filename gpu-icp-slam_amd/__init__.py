@@ -10,6 +10,6 @@ The directory name contains a hyphen; import it with
     importlib.import_module("gpu-icp-slam_amd")
 """
 from .binding import (NODE_DTYPE, PARTICLE_DTYPE, Config, PfSlam, PfSlamError, kd_balance, kd_create,  # noqa: F401
-                      kd_insert_node, load, device_count)
+                      kd_insert_node, load, device_count, MgpuRank, mgpu_make_id, load_mgpu)
 from . import synth  # noqa: F401
 from .build import build  # noqa: F401

@@ -17,7 +17,7 @@ PARTICLE_DTYPE = np.dtype(
 # every symbol include/pfslam.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "pfslam_default_config", "pfslam_create", "pfslam_destroy", "pfslam_last_error", "pfslam_device_count",
-    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_disperse", "pfslam_shard_score", "pfslam_shard_weights", "pfslam_shard_finish", "pfslam_get_pose", "pfslam_get_particles",
+    "pfslam_set_stream", "pfslam_synchronize", "pfslam_step", "pfslam_step_grid", "pfslam_shard_disperse", "pfslam_shard_score", "pfslam_shard_weights", "pfslam_shard_finish", "pfslam_shard_stream", "pfslam_get_pose", "pfslam_get_particles",
     "pfslam_get_map", "pfslam_get_grid", "pfslam_get_trace", "pfslam_get_cells", "pfslam_set_map",
     "pfslam_set_particles", "pfslam_shift_particles", "pfslam_set_scan", "pfslam_set_pose", "pfslam_set_grid", "pfslam_motion_update",
     "pfslam_score_kd", "pfslam_measurement_update", "pfslam_icp", "pfslam_update_map_kd", "pfslam_resample",
@@ -25,7 +25,7 @@ SYMBOLS = [
     "pfslam_measurement_apply", "pfslam_device_ptr", "pfslam_time_score_kd", "pfslam_set_variant", "pfslam_set_lag",
     "pfslam_kd_create", "pfslam_kd_insert_list", "pfslam_kd_insert_node", "pfslam_kd_balance", "pfslam_set_timing", "pfslam_get_timers", "pfslam_resample_plan", "pfslam_resample_gather", "pfslam_maybe_balance", "pfslam_kd_size", "pfslam_topology_update", "pfslam_find_walls",
     "pfslam_check_loop_closure", "pfslam_get_topology", "pfslam_set_topology", "pfslam_get_closures", "pfslam_score_census", "pfslam_set_census", "pfslam_get_census_log", "pfslam_ubench_gather", "pfslam_plan_stats", "pfslam_cell_stats", "pfslam_kd_parallel_sort", "pfslam_kd_sort_threads", "pfslam_kd_whole_node",
-    "pfslam_set_serial", "pfslam_debug_check_cells", "pfslam_set_probe", "pfslam_get_probe", "pfslam_probe_name", "pfslam_frame_mode",
+    "pfslam_set_serial", "pfslam_set_trig", "pfslam_debug_check_cells", "pfslam_set_probe", "pfslam_get_probe", "pfslam_probe_name", "pfslam_frame_mode",
     "pfslam_time_score_grid", "pfslam_set_shard_balance", "pfslam_shard_balance_due", "pfslam_shard_balance_build", "pfslam_shard_balance_adopt",
 ]
 
@@ -97,6 +97,7 @@ def load():
     L.pfslam_shard_score.argtypes = [vp]
     L.pfslam_shard_weights.argtypes = [vp]
     L.pfslam_shard_finish.argtypes = [vp]
+    L.pfslam_shard_stream.argtypes = [vp, i32, vp]
     L.pfslam_time_score_grid.argtypes = [vp, i32, vp, vp]
     L.pfslam_set_shard_balance.argtypes = [vp, i32]
     L.pfslam_shard_balance_due.argtypes = [vp, i32, vp, vp]
@@ -137,6 +138,7 @@ def load():
     L.pfslam_plan_stats.argtypes = [vp, vp]
     L.pfslam_cell_stats.argtypes = [vp, vp]
     L.pfslam_set_serial.argtypes = [vp, i32]
+    L.pfslam_set_trig.argtypes = [vp, i32]
     L.pfslam_debug_check_cells.argtypes = [vp, vp]
     L.pfslam_set_probe.argtypes = [vp, i32]
     L.pfslam_get_probe.argtypes = [vp, vp, i32, vp, vp]
@@ -191,6 +193,85 @@ def kd_insert_node(nodes, size, p4):
 
 def kd_balance(nodes, size):
     _chk(load().pfslam_kd_balance(_p(nodes), size), "pfslam_kd_balance")
+
+
+# ---- libpfslam_mgpu.so: the sharded frame with its all-gathers on librccl, launched into the frame's own streams (include/pfslam_mgpu.h)
+MGPU_SYMBOLS = ["pfslam_mgpu_make_id", "pfslam_mgpu_create", "pfslam_mgpu_destroy", "pfslam_mgpu_step", "pfslam_mgpu_barrier_max",
+                "pfslam_mgpu_stats", "pfslam_mgpu_time_collectives", "pfslam_mgpu_last_error"]
+MGPU_ID_BYTES = 256
+_mgpu = None
+
+
+def load_mgpu():
+    """ctypes handle of host/libpfslam_mgpu.so (built by `make -C gpu-icp-slam_amd/host`, which __graft_entry__.build() runs)."""
+    global _mgpu
+    if _mgpu is not None:
+        return _mgpu
+    load()  # (libpfslam_hip.so first: the multi-GPU library links it)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libpfslam_mgpu.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.dirname(path), "libpfslam_mgpu.so"], stdout=subprocess.DEVNULL)
+    M = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i32 = C.c_void_p, C.c_int32
+    M.pfslam_mgpu_last_error.restype = C.c_char_p
+    M.pfslam_mgpu_make_id.argtypes = [vp]
+    M.pfslam_mgpu_create.argtypes = [vp, i32, i32, vp, vp]
+    M.pfslam_mgpu_destroy.argtypes = [vp]
+    M.pfslam_mgpu_step.argtypes = [vp, i32, vp]
+    M.pfslam_mgpu_barrier_max.argtypes = [vp, vp]
+    M.pfslam_mgpu_stats.argtypes = [vp, vp]
+    M.pfslam_mgpu_time_collectives.argtypes = [vp, i32, vp]
+    _mgpu = M
+    return M
+
+
+def mgpu_make_id():
+    """The job id rank 0 makes (two ncclUniqueId); the caller carries the bytes to the other ranks."""
+    M = load_mgpu()
+    buf = (C.c_ubyte * MGPU_ID_BYTES)()
+    if M.pfslam_mgpu_make_id(buf):
+        raise PfSlamError("pfslam_mgpu_make_id failed: %s" % M.pfslam_mgpu_last_error().decode())
+    return bytes(buf)
+
+
+class MgpuRank:
+    """One rank of a sharded job stepped natively: pfslam_mgpu_step = the four pfslam_shard_* calls with the three RCCL all-gathers
+    launched straight into the frame's own streams."""
+
+    def __init__(self, eng, world, rank, job_id=None):
+        self.M, self.eng = load_mgpu(), eng
+        self._m = C.c_void_p(0)
+        idbuf = (C.c_ubyte * MGPU_ID_BYTES).from_buffer_copy(job_id) if job_id is not None else None
+        self._chk(self.M.pfslam_mgpu_create(idbuf, world, rank, eng._h, C.byref(self._m)), "pfslam_mgpu_create")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PfSlamError("%s failed: %s" % (what, self.M.pfslam_mgpu_last_error().decode()))
+
+    def step(self, frame, scan):
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        self._chk(self.M.pfslam_mgpu_step(self._m, frame, _p(scan)), "pfslam_mgpu_step")
+
+    def barrier_max(self, value=None):
+        v = C.c_double(0.0 if value is None else value)
+        self._chk(self.M.pfslam_mgpu_barrier_max(self._m, C.byref(v) if value is not None else None), "pfslam_mgpu_barrier_max")
+        return v.value
+
+    def stats(self):
+        out = (C.c_int * 4)()
+        self._chk(self.M.pfslam_mgpu_stats(self._m, out), "pfslam_mgpu_stats")
+        return {"collectives": out[0], "balance_builds": out[1], "balance_broadcasts": out[2], "world": out[3]}
+
+    def time_collectives(self, reps=20):
+        ms = (C.c_float * 3)()
+        self._chk(self.M.pfslam_mgpu_time_collectives(self._m, reps, ms), "pfslam_mgpu_time_collectives")
+        return {"pose_blocks": ms[0], "records": ms[1], "weights": ms[2]}
+
+    def close(self):
+        if self._m:
+            self.M.pfslam_mgpu_destroy(self._m)
+            self._m = C.c_void_p(0)
 
 
 class PfSlam:
@@ -426,6 +507,10 @@ class PfSlam:
         d["violations"] = sum(v for k, v in d.items() if k.startswith("v_"))
         return d
 
+    def set_trig(self, devlib):
+        """1: the device library's cosf / sinf / erfcinvf instead of the pf_math.h specification (include/pfslam.h, pfslam_set_trig)."""
+        _chk(self.L.pfslam_set_trig(self._h, 1 if devlib else 0), "pfslam_set_trig")
+
     def frame_mode(self):
         out = (C.c_int * 4)()
         _chk(self.L.pfslam_frame_mode(self._h, out), "pfslam_frame_mode")
@@ -488,6 +573,12 @@ class PfSlam:
 
     def shard_finish(self):
         _chk(self.L.pfslam_shard_finish(self._h), "pfslam_shard_finish")
+
+    def shard_stream(self, which):
+        """hipStream_t (as an int) collective `which` (0 pose blocks, 1 keys, 2 weights) of the frame being enqueued goes into."""
+        st = C.c_void_p(0)
+        _chk(self.L.pfslam_shard_stream(self._h, which, C.byref(st)), "pfslam_shard_stream")
+        return st.value or 0
 
     # -- multi-GPU re-balance: one host build per node (include/pfslam.h)
     def set_shard_balance(self, external):

@@ -301,7 +301,7 @@ __device__ __forceinline__ float lidar_angle(int n)
     return fdiv((-135.0f + (float)n * .25f) * PI_F, 180.0f);
 }
 // the hot loops: the beam's angle and parts from a per-beam table (wave-uniform scalars), the heading's parts once per particle
-template <bool GUARD = true>
+template <int GUARD = 1>
 __device__ __forceinline__ void clean_lidar_scan_parts(float angle, const AngleParts &A, float range, float theta, const AngleParts &T,
                                                        float &x, float &y)
 {
@@ -311,10 +311,11 @@ __device__ __forceinline__ void clean_lidar_scan_parts(float angle, const AngleP
     x = range * c;
     y = range * s;
 }
-__device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y)
+__device__ __forceinline__ void clean_lidar_scan(int n, float range, float theta, float &x, float &y, int trig = 0)
 {
     const float angle = lidar_angle(n);
-    clean_lidar_scan_parts(angle, angle_parts(angle), range, theta, angle_parts(theta), x, y);
+    if (trig) clean_lidar_scan_parts<PF_TRIG_DEVLIB>(angle, AngleParts{0.0, 0.0, 0.0}, range, theta, AngleParts{0.0, 0.0, 0.0}, x, y); // (pfslam_set_trig)
+    else clean_lidar_scan_parts(angle, angle_parts(angle), range, theta, angle_parts(theta), x, y);
 }
 // per-beam table entry: {cos, sin, angle as double, angle as float (low half of the 4th double's slot)}
 struct BeamParts { double c, s, a; float angle, pad; };

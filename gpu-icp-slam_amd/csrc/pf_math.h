@@ -121,9 +121,20 @@ PF_HD AngleParts angle_parts(float angle)
 // GUARD false: the caller knows every heading it will see is below the bound (the scan-match kernel of the cell rows, told by the
 // host: the direct form's registers cost that kernel two of its eight waves per SIMD and 12 % of its time -- 79 instead of 60 VGPRs,
 // 0.488 instead of 0.433 ms per scoring pass, tools/experiments/r04/ab_big_theta.sh -- although no lane ever takes the branch).
-template <bool GUARD = true>
+// GUARD 2 (PF_TRIG_DEVLIB, pfslam_set_trig): not the specification at all but the device library's cosf / sinf of rot -- what the
+// reference's own text (std::cos / std::sin, kernel.cu:185-186) compiles to on this platform.  The mode exists for ONE purpose: with
+// it the product's kernels must equal the reference's kernels compiled for gfx950 (oracle/_ref/kernel_ref.hsaco) with ZERO mismatches,
+// which isolates everything else the product does differently (cell rows, lane order, reductions) from the last-ulp choice of the
+// transcendentals.  Off by default: the specification is what the CPU oracle can follow bit for bit.
+#define PF_TRIG_DEVLIB 2
+template <int GUARD = 1>
 PF_HD void sincos_sum_spec(const AngleParts &A, const AngleParts &T, float rot, float &s, float &c)
 {
+    if (GUARD == PF_TRIG_DEVLIB) {
+        s = ::sinf(rot);
+        c = ::cosf(rot);
+        return;
+    }
     if (GUARD && !(fabs(T.a) < (double)PF_SUM_THETA_MAX)) { // (a NaN heading too)
         sincosf_spec(rot, s, c);
         return;
@@ -174,7 +185,10 @@ PF_HD double log_spec(double x)
 }
 
 // Inverse normal CDF (Cephes ndtri -- the routine behind thrust's erfcinv), mul/add unfused.
-PF_HD double ndtri_spec(double y0)
+// DEVLOG: the natural logarithm of the device library instead of log_spec -- rocThrust's own ndtri (thrust/random/detail/erfcinv.h, the
+// routine its normal_distribution calls on this platform) compiled for the device: same operations, same order, its log is ::log.
+template <bool DEVLOG>
+PF_HD double ndtri_t(double y0)
 {
     const double s2pi = 2.50662827463100050242E0;
     const double EXPM2 = 0.13533528323661269189;
@@ -205,8 +219,8 @@ PF_HD double ndtri_spec(double y0)
         x = x * s2pi;
         return x;
     }
-    x = sqrt(-2.0 * log_spec(y));
-    x0 = x - log_spec(x) / x;
+    x = sqrt(-2.0 * (DEVLOG ? ::log(y) : log_spec(y)));
+    x0 = x - (DEVLOG ? ::log(x) : log_spec(x)) / x;
     z = 1.0 / x;
     double p, q;
     if (x < 8.0) {
@@ -251,6 +265,8 @@ PF_HD double ndtri_spec(double y0)
     if (code != 0) x = -x;
     return x;
 }
+
+PF_HD double ndtri_spec(double y0) { return ndtri_t<false>(y0); }
 
 PF_HD float erfcinvf_spec(float y)
 {
@@ -312,7 +328,9 @@ PF_HD float uniform_real(uint32_t &state, float a, float b)
     result = fdiv(result, 1.0f + (float)(2147483646u - 1u));
     return (result * (b - a)) + a;
 }
-PF_HD float normal(uint32_t &state, float mean, float stddev)
+// devlib: rocThrust's own arithmetic instead of the specification (pfslam_set_trig, see sincos_sum_spec).  The specification follows CUDA's
+// thrust, where erfcinv(2 * p) of a float is CUDA's float erfcinvf and the expression stays in float.
+PF_HD float normal(uint32_t &state, float mean, float stddev, bool devlib = false)
 {
     const uint32_t urng_range = 2147483646u - 1u;
     const float S1 = 4.656612873077392578125e-10f; // 1.0f / (float)urng_range == 2^-31
@@ -324,6 +342,19 @@ PF_HD float normal(uint32_t &state, float mean, float stddev)
         S3 = -S3;
     }
     float p = (float)u * S1 + S2;
+    if (devlib) {
+        // rocThrust's normal_distribution as the reference's text compiles it here: `mean + stddev * S3 * erfcinv(2 * p)` with thrust's own
+        // erfcinv(double) -- the product stddev * S3 in float, everything behind it in double, ONE rounding to float at the return; its
+        // constant one_o_sqrt2 is the double quotient 1 / sqrt(2.0), one ulp below the nearest double to 2^-1/2
+        const double x = (double)(2 * p);
+        const double one_o_sqrt2 = 1.0 / 1.4142135623730951; // (1 / sqrt(2.0)), folded
+        double e;
+        if (x < 0.0 || x > 2.0) e = (double)NAN;
+        else if (x == 0.0) e = (double)INFINITY;
+        else if (x == 2.0) e = -(double)INFINITY;
+        else e = -ndtri_t<true>(0.5 * x) * one_o_sqrt2;
+        return (float)((double)mean + (double)(stddev * S3) * e);
+    }
     return mean + stddev * S3 * erfcinvf_spec(2 * p);
 }
 

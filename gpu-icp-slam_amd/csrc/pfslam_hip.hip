@@ -96,9 +96,11 @@ struct pfslam_handle {
     // [world][x | y | theta]; they alias the local arrays when not sharded
     float *gw = nullptr, *gpose = nullptr;
     bool own_global = false;
-    // sharded measurement merge: this rank's {max key, negated-min key, pose of its best particle} (32 bytes) and the
-    // all-gathered records of every rank
-    long long *pack = nullptr, *packs = nullptr;
+    // sharded measurement merge: a rank's record is its packed {max key, negated-min key} (16 bytes: h->stats / the frame ring's
+    // fstats by ticket parity); gkeys = the all-gathered records of every rank (world x 16 bytes), mkeys = their merge (-> header),
+    // gtheta = largest |heading| over every rank's pose block, ring of 4 by ticket (k_theta_gmax)
+    long long *gkeys = nullptr, *mkeys = nullptr;
+    float *gtheta = nullptr;
     float *scan = nullptr;      // the current frame's scan on the device: one of the PF_HDR_SLOTS slots of scan_base
     float *scan_base = nullptr; // (the map update of frame t may still read its scan while frame t + 1's is uploaded)
     // map
@@ -154,11 +156,19 @@ struct pfslam_handle {
     // device, there is no idle gap between frames.  Any other entry point settles the frames in flight first (settle()).
     HostHeader *h_hdr = nullptr, *hdr_dev = nullptr; // PF_HDR_SLOTS pinned headers and their device view
     float *h_scan = nullptr;                         // PF_HDR_SLOTS pinned scan staging buffers
-    struct Frame { int seq, frame, kind; bool boxes = false; bool v2 = false; }; // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once); boxes: its scoring pass made pose boxes (theta_max of its header is this frame's)
+    struct Frame { int seq, frame, kind; bool boxes = false; bool v2 = false; bool gtheta = false; }; // kind 0 = KD step, 1 = 2-D step, 2 = seed / sharded (settled at once); boxes: its scoring pass made pose boxes (theta_max of its header is this frame's)
     std::deque<Frame> in_flight;
     int seq = 0; // tickets handed out
     int cur_seq = 0, cur_frame = 0; // the frame being enqueued (frame_front .. frame_tail)
     int shard_stage = 0;            // sharded frame: 1 dispersed, 2 scored, 3 weights done (call order check)
+    bool shard_v2 = false;          // the sharded frame being enqueued is a cut of the round-5 frame (else: the staged round-4 chain, every collective on the handle's stream)
+    bool shard_call = false;        // the frame being enqueued came in through pfslam_shard_*
+    bool theta_global_known = true; // sharded jobs: a header with the job-wide |heading| maximum has been booked since the particles were last set
+    struct FrameV2 { int used = 0, bpc = 0, frame = 0; bool sync_cells = false, serial = false, sharded = false, gates = false, ftail_gate = false; } fv; // the round-5 frame being enqueued, between its parts
+    bool gates_tested = false;      // the self-test of the four streams has run since they last changed (pfslam_set_stream)
+    bool gates_ok = false;          // ... and they make progress independently of one another
+    bool gates_live = false;        // the frames in flight use gates (a change of mode drains the pipeline first)
+    hipEvent_t ev_poseg = nullptr;  // events mode, sharded: the gathered pose blocks are there (P -> C)
     int lag = 1; // frames the host may run ahead (PFSLAM_LAG; 0 = every step settles itself)
     float scan_reach = 8.0f; // mean in-range beam length of the current scan (m): the lever arm of a heading difference
     std::vector<pfslam_particle> h_particles;
@@ -243,6 +253,7 @@ struct pfslam_handle {
     pf::BeamParts *beam_angle = nullptr; // LIDAR_ANGLE(j) and its cos / sin as doubles, nb entries
     float *fit_acc = nullptr;    // per-lane score accumulators of the cell-row kernel (zero between passes)
     // ---- round-5 frame loop (pfslam_frame.hip.inc): four in-order chains, a fixed set of events between them ----
+    int trig = 0;                 // pfslam_set_trig: 1 = the device library's cosf / sinf / erfcinvf instead of the pf_math.h specification (see sincos_sum_spec)
     int serial = 0;               // PFSLAM_SERIAL=1: every frame's launches on ONE stream, in enqueue order (same results, same bookkeeping)
     int frame_v2 = 1;             // PFSLAM_FRAME_V2=0: the round-4 frame (A/B runs)
     bool pipe_live = false;       // the last frame was a round-5 frame: its events and ring slots are what the next one waits on
@@ -301,16 +312,16 @@ static_assert(PB_END <= PF_PROBE_SLOTS, "probe slots");
 // weights of the second half to their pre-measurement values.
 __global__ __launch_bounds__(256) void k_motion(float *__restrict__ x, float *__restrict__ y,
                                                 float *__restrict__ th, float *__restrict__ w,
-                                                const float *__restrict__ wm, int n, int frame, int goff)
+                                                const float *__restrict__ wm, int n, int frame, int goff, int trig = 0)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     w[i] = wm[i];
     uint32_t e2 = pf::engine_seed(frame, goff + i, 0);
     const float sx = 0.015, sy = 0.015, st = .01; // COV, kernel.cu:45 (used as std-dev, H10)
-    float nx = pf::normal(e2, 0.0f, sx);
-    float ny = pf::normal(e2, 0.0f, sy);
-    float nt = pf::normal(e2, 0.0f, st);
+    float nx = pf::normal(e2, 0.0f, sx, trig != 0);
+    float ny = pf::normal(e2, 0.0f, sy, trig != 0);
+    float nt = pf::normal(e2, 0.0f, st, trig != 0);
     x[i] += nx;
     y[i] += ny;
     th[i] += nt;
@@ -326,12 +337,19 @@ __global__ void k_beam_angles(pf::BeamParts *__restrict__ beams, int nb)
     const pf::AngleParts p = pf::angle_parts(angle);
     beams[j] = pf::BeamParts{p.c, p.s, p.a, angle, 0.0f};
 }
-template <bool GUARD = true>
+template <int GUARD = 1>
 __device__ __forceinline__ void beam_end_point(const pf::BeamParts *__restrict__ beams, int j, float range, float theta, const pf::AngleParts &T,
                                                float &x, float &y)
 {
     const pf::BeamParts bp = beams[j]; // wave-uniform: scalar loads
     pf::clean_lidar_scan_parts<GUARD>(bp.angle, pf::AngleParts{bp.c, bp.s, bp.a}, range, theta, T, x, y);
+}
+// ... with the trigonometry chosen at run time (pfslam_set_trig; every kernel but the cell-row scan-match kernel, which is instantiated for it)
+__device__ __forceinline__ void beam_end_point_rt(const pf::BeamParts *__restrict__ beams, int j, float range, float theta, const pf::AngleParts &T,
+                                                  float &x, float &y, int trig)
+{
+    if (trig) beam_end_point<PF_TRIG_DEVLIB>(beams, j, range, theta, T, x, y);
+    else beam_end_point(beams, j, range, theta, T, x, y);
 }
 
 // ---- A5: scan-match score (EvaluateParticleKD / kernEvaluateParticlesKD, kernel.cu:1198-1308)
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
                                                   const float *__restrict__ pth, int n,
                                                   const float *__restrict__ scan, const pf::BeamParts *__restrict__ beams, int nb,
                                                   int beams_per_chunk, pf::KdView tree, const int *__restrict__ order, int direct,
-                                                  float *__restrict__ out, pf::KdCensus *__restrict__ census = nullptr)
+                                                  float *__restrict__ out, pf::KdCensus *__restrict__ census = nullptr, int trig = 0)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int j0 = blockIdx.y * beams_per_chunk;
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(256) void k_score_kd(const float *__restrict__ px, 
     pf::KdCensusLocal cl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = j0; j < j1; j++) {
         float wx, wy;
-        beam_end_point(beams, j, scan[j], th, T, wx, wy);
+        beam_end_point_rt(beams, j, scan[j], th, T, wx, wy, trig);
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;
             wy += y;
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ 
                                                       const pf::BeamParts *__restrict__ beams, int nb,
                                                       int beams_per_chunk, pf::KdView tree, const pf::KdPlanRow *__restrict__ plan,
                                                       const int *__restrict__ order, int direct, float *__restrict__ out,
-                                                      pf::KdCensus *__restrict__ census = nullptr)
+                                                      pf::KdCensus *__restrict__ census = nullptr, int trig = 0)
 {
     const int g = blockIdx.x, slot = g * 64 + threadIdx.x;
     const int j0 = blockIdx.y * beams_per_chunk;
@@ -528,7 +546,7 @@ __global__ __launch_bounds__(64) void k_score_kd_plan(const float *__restrict__ 
             cur = nxt;
             continue;
         }
-        beam_end_point(beams, j, cur.range, th, T, wx, wy);
+        beam_end_point_rt(beams, j, cur.range, th, T, wx, wy, trig);
         if (fabsf(wx) < PF_LIDAR_RANGE && fabsf(wy) < PF_LIDAR_RANGE) {
             wx += x;
             wy += y;
@@ -820,6 +838,13 @@ static int join_map(pfslam_handle *h); // main stream waits for the map update a
 
 extern "C" int pfslam_destroy(pfslam_handle *h);
 
+// Handles alive in this process.  The stream gates of the round-5 frame (pfslam_frame.hip.inc) spin inside kernels and are only safe
+// when the streams involved sit on hardware queues of their own: that is self-tested for ONE handle's four streams, but the runtime
+// pools a handful of hardware queues per priority, so the streams of two handles may share one -- and two handles with frames in flight
+// could then wait on each other (h1's signal queued behind h2's gate and vice versa) until the gates give up.  So: gates only while a
+// handle is the process's only one; with a second handle alive every handle's edges are events (PFSLAM_GATES=0 forces that too).
+static std::atomic<int> g_live_handles{0};
+
 // allocations and initial state of a handle; on failure the caller destroys the partially built handle
 static int create_impl(pfslam_handle *h)
 {
@@ -872,7 +897,8 @@ static int create_impl(pfslam_handle *h)
     HIPCHK(hipMemsetAsync(h->wm, 0, S * 4, h->stream));
     h->x = h->pblk; h->y = h->pblk + S; h->th = h->pblk + 2 * S;
     h->x2 = h->pblk2; h->y2 = h->pblk2 + S; h->th2 = h->pblk2 + 2 * S;
-    CHK(dalloc(&h->pack, 4)); CHK(dalloc(&h->packs, (size_t)4 * h->world));
+    CHK(dalloc(&h->gkeys, (size_t)2 * h->world)); CHK(dalloc(&h->mkeys, 2)); CHK(dalloc(&h->gtheta, 4));
+    HIPCHK(hipMemsetAsync(h->gtheta, 0, 16, h->stream));
     if (h->gn != h->n) {
         // rank r owns [r * stride, min((r + 1) * stride, gn)): every rank but the last is full, the last one is not empty
         if (h->goff < 0 || h->goff % h->stride != 0 || h->n > h->stride || h->goff + h->n != std::min(h->goff + h->stride, h->gn))
@@ -972,6 +998,7 @@ extern "C" int pfslam_create(const pfslam_config *cfg, pfslam_handle **out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail("pfslam_create: bad device ordinal");
     HIPCHK(hipSetDevice(cfg->device));
     pfslam_handle *h = new pfslam_handle();
+    g_live_handles.fetch_add(1);
     h->cfg = *cfg;
     const int rc = create_impl(h);
     if (rc) { // release whatever was allocated before the failure; g_err keeps the message of the failure
@@ -990,7 +1017,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)settle(h); // frames in flight finish first (their deferred errors are the caller's to collect: pfslam_synchronize)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->pack, h->packs, h->scan_base, h->hot, h->parent, h->kz, h->kw,
+    void *bufs[] = {h->pblk, h->pblk2, h->w, h->wm, h->gkeys, h->mkeys, h->gtheta, h->scan_base, h->hot, h->parent, h->kz, h->kw,
                     h->fit, h->fit_i, h->partial, h->mkey, h->order2, h->cells, h->stats, h->pose, h->start, h->icp_tar, h->icp_cor, h->icp_dbg,
                     h->free_mask, h->blk_cnt, h->wall_cell, h->free_cell, h->wall_pts, h->free_pts,
                     h->wall_c, h->free_c, h->counts, h->tile_r, h->tile_r2, h->sums, h->cdf,
@@ -1037,6 +1064,7 @@ extern "C" int pfslam_destroy(pfslam_handle *h)
     frame_free(h);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    g_live_handles.fetch_sub(1);
     return 0;
 }
 
@@ -1051,6 +1079,7 @@ extern "C" int pfslam_set_stream(pfslam_handle *h, void *hip_stream)
     }
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
+    h->gates_tested = false; // the gates' self-test saw the old stream: it runs again in front of the next round-5 frame
     return 0;
 }
 
@@ -1303,6 +1332,7 @@ extern "C" int pfslam_set_particles(pfslam_handle *h, const pfslam_particle *p, 
         for (int i = 0; i < n; i++) tb = p[i].theta == p[i].theta ? std::max(tb, fabsf(p[i].theta)) : INFINITY;
         h->theta_bound = tb;
         h->theta_shift = 0.0f;
+        if (h->world > 1) h->theta_global_known = false; // (this call saw one shard's headings only)
         h->cloud_valid = false; // (round-5 frames: k_motion_count's statistics describe the cloud this call replaces)
     }
     HIPCHK(hipMemcpyAsync(h->x, &tmp[0], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -1453,7 +1483,7 @@ extern "C" int pfslam_motion_update(pfslam_handle *h, int frame)
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(settle_staged(h));
     hipLaunchKernelGGL(k_motion, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->x, h->y, h->th, h->w, h->wm,
-                       h->n, frame, h->goff);
+                       h->n, frame, h->goff, h->trig);
     HIPCHK(hipGetLastError());
     h->theta_bound += 0.1f;
     return 0;
@@ -1602,10 +1632,8 @@ static bool org_use_cells(const pfslam_handle *h, bool *use_plan, bool frame_loo
     if (use_plan) *use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);
     return use_cells;
 }
-struct ShardPack;
 __global__ void k_reduce_partials_minmax(float *partial, int n, int chunks, const int *order, float *fit, int goff, long long *stats,
-                                         const float *x, const float *y, const float *th, ShardPack *pack, int wipe, int p16);
-__global__ void k_shard_pack(const long long *stats, const float *x, const float *y, const float *th, int n, int goff, ShardPack *pack);
+                                         const float *x, const float *y, const float *th, int wipe, int p16);
 __global__ void k_reduce_partials_minmax_wide(const float *partial, int n, int chunks, const int *order, float *fit, long long *stats);
 template <typename T> __global__ void k_minmax(const T *fit, int n, int goff, long long *stats);
 static int join_icp(pfslam_handle *h);
@@ -1614,7 +1642,7 @@ static int launch_stats_reset(pfslam_handle *h, hipStream_t st);
 // fuse_minmax: the frame loops want the packed min/max keys of this shard right away; the reduce kernel then produces them
 // too (one launch less on the chain).  Needs more than one beam chunk, which every launch below ~8 M particles has.
 // census: run the counting instantiation of the score kernel instead (same launch shape, same results).
-static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus *census = nullptr, bool shard_pack = false)
+static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus *census = nullptr, bool sharded = false)
 {
     if (h->kd_size <= 0) return fail("pfslam_score_kd: no map loaded");
     const int chunks = score_chunks(h);
@@ -1693,7 +1721,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     const bool acc_out = acc_enabled && use_cells && h->integral_w && used > 1 && fuse_minmax && !census;
     const int direct = used > 1 ? 0 : 1;
     // beam-chunk partials of the cell-row kernel as 16-bit integers: integer weights, and a chunk's sum cannot leave the range
-    const bool wide_reduce = used >= 256 && fuse_minmax && !shard_pack && h->goff == 0 && !acc_out;
+    const bool wide_reduce = used >= 256 && fuse_minmax && !sharded && h->goff == 0 && !acc_out;
     static const bool p16_ok = !(getenv("PFSLAM_P16") && atoi(getenv("PFSLAM_P16")) == 0);
     const bool p16 = p16_ok && use_cells && h->integral_w && used > 1 && fuse_minmax && !acc_out && !wide_reduce && (float)bpc * h->w_absmax <= 32767.0f;
     h->plan_valid = use_plan;
@@ -1764,7 +1792,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // order -- is shorter than the map update and off the chain.  With the scan-match kernel on this stream, the chain crossed
     // streams twice per frame (fork behind the best pose, join in front of the next scan-match), 12-17 us each.
     static const bool aux_ok = !(getenv("PFSLAM_SCORE_ON_AUX") && atoi(getenv("PFSLAM_SCORE_ON_AUX")) == 0);
-    const bool on_aux = aux_ok && h->score_on_aux && use_cells && !cells_sync && fuse_minmax && !census && !shard_pack;
+    const bool on_aux = aux_ok && h->score_on_aux && use_cells && !cells_sync && fuse_minmax && !census && !sharded;
     h->scored_on_aux = on_aux;
     struct StreamSwap { // the rest of this function launches on h->stream: point it at the aux stream for that long
         pfslam_handle *h;
@@ -1788,29 +1816,31 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
             // no heading anywhere near the bound of the angle-addition sincos (the host's running bound, refreshed from every frame's
             // header): the instantiation without the direct form -- 60 instead of 79 VGPRs, 8 instead of 6 waves per SIMD
             const bool guard = !(h->theta_bound < 0.5f * PF_SUM_THETA_MAX) || h->own_global; // (a shard imports particles at every resample: always guarded)
-            if (cen) hipLaunchKernelGGL((k_score_kd_cells<true, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : p16 ? 3 : 0, cen);
+            if (h->trig && cen) hipLaunchKernelGGL((k_score_kd_cells<true, PF_TRIG_DEVLIB>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : p16 ? 3 : 0, cen);
+            else if (h->trig) hipLaunchKernelGGL((k_score_kd_cells<false, PF_TRIG_DEVLIB>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : p16 ? 3 : 0, (pf::KdCensus *)nullptr);
+            else if (cen) hipLaunchKernelGGL((k_score_kd_cells<true, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 2 : p16 ? 3 : 0, cen);
             else if (guard) hipLaunchKernelGGL((k_score_kd_cells<false, true>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : p16 ? 3 : 0, (pf::KdCensus *)nullptr);
             else hipLaunchKernelGGL((k_score_kd_cells<false, false>), PF_CELLS_ARGS, acc_out ? h->fit_acc : out, acc_out ? 1 : p16 ? 3 : 0, (pf::KdCensus *)nullptr);
 #undef PF_CELLS_ARGS
         } else if (use_plan) {
             if (cen)
                 hipLaunchKernelGGL((k_score_kd_plan<true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
-                                   kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, cen);
+                                   kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, cen, h->trig);
             else
                 hipLaunchKernelGGL((k_score_kd_plan<false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
-                                   kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, (pf::KdCensus *)nullptr);
+                                   kd_view(h), (const pf::KdPlanRow *)h->plan, order, direct, out, (pf::KdCensus *)nullptr, h->trig);
         } else if (h->planar && cen)
             hipLaunchKernelGGL((k_score_kd<true, true>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
-                               kd_view(h), order, direct, out, cen);
+                               kd_view(h), order, direct, out, cen, h->trig);
         else if (cen)
             hipLaunchKernelGGL((k_score_kd<false, true>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
-                               kd_view(h), order, direct, out, cen);
+                               kd_view(h), order, direct, out, cen, h->trig);
         else if (h->planar)
             hipLaunchKernelGGL((k_score_kd<true, false>), grid64, dim3(64), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
-                               kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
+                               kd_view(h), order, direct, out, (pf::KdCensus *)nullptr, h->trig);
         else
             hipLaunchKernelGGL((k_score_kd<false, false>), grid256, dim3(256), 0, h->stream, h->x, h->y, h->th, h->n, h->scan, (const pf::BeamParts *)h->beam_angle, h->nb, bpc,
-                               kd_view(h), order, direct, out, (pf::KdCensus *)nullptr);
+                               kd_view(h), order, direct, out, (pf::KdCensus *)nullptr, h->trig);
     };
     if (use_plan || use_cells) {
         const int groups = (h->n + 63) / 64;
@@ -1854,8 +1884,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
 #define PF_REDUCE4_WGS 128 /* workgroups of k_reduce_partials_minmax (grid-stride over the slots; see the kernel) */
         static const int reduce4_wgs = getenv("PFSLAM_REDUCE4_WGS") ? std::max(1, atoi(getenv("PFSLAM_REDUCE4_WGS"))) : PF_REDUCE4_WGS; // (A/B: 1000000 = one workgroup per 256 slots)
         hipLaunchKernelGGL(k_reduce_partials_minmax, dim3(std::min((h->n + 255) / 256, reduce4_wgs)), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
-                           acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th,
-                           shard_pack ? (ShardPack *)h->pack : (ShardPack *)nullptr, acc_out ? 1 : 0, p16 ? 1 : 0);
+                           acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th, acc_out ? 1 : 0, p16 ? 1 : 0);
         HIPCHK(hipGetLastError());
     } else {
         if (used > 1) {
@@ -1866,11 +1895,6 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         if (fuse_minmax) { // single chunk: the score kernel wrote fit directly
             const int blocks = std::min(1024, (h->n + 255) / 256);
             hipLaunchKernelGGL(k_minmax<float>, dim3(blocks), dim3(256), 0, h->stream, (const float *)h->fit, h->n, h->goff, (long long *)h->stats);
-            HIPCHK(hipGetLastError());
-        }
-        if (fuse_minmax && shard_pack) { // single beam chunk (> 8 M particles or non-integral map weights): the record in its own launch
-            hipLaunchKernelGGL(k_shard_pack, dim3(1), dim3(64), 0, h->stream, (const long long *)h->stats, h->x, h->y, h->th, h->n, h->goff,
-                               (ShardPack *)h->pack);
             HIPCHK(hipGetLastError());
         }
     }
@@ -2205,12 +2229,23 @@ extern "C" int pfslam_frame_mode(pfslam_handle *h, int out[4])
 {
     if (!h || !out) return fail("pfslam_frame_mode: bad argument");
     out[0] = h->pipe_live ? 1 : 0;
-    out[1] = h->gates;
+    out[1] = h->pipe_live ? (h->gates_live ? 1 : 0) : h->gates; // (frames in flight: what they use -- gates are withdrawn while the process holds a second handle)
     out[2] = h->serial;
     out[3] = h->publish_lag;
     return 0;
 }
 extern "C" const char *pfslam_probe_name(int slot) { return slot >= 0 && slot < PB_END ? pb_names[slot] : ""; }
+// 0 (default): the transcendentals of pf_math.h (fixed sequences of double operations, what the CPU oracle follows bit for bit).  1: the
+// device library's cosf / sinf in CleanLidarScan and erfcinvf in the dispersion -- what the reference's text compiles to on this platform;
+// with it the product's kernels equal the reference's own kernels built for gfx950 with zero mismatches (tests/test_gpu_ref_kernels.py).
+extern "C" int pfslam_set_trig(pfslam_handle *h, int devlib)
+{
+    if (!h || devlib < 0 || devlib > 1) return fail("pfslam_set_trig: 0 (specification) or 1 (device library)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(settle(h));
+    h->trig = devlib;
+    return 0;
+}
 // 1: every frame's launches on one stream, in enqueue order (what PFSLAM_SERIAL=1 sets at creation); same results, same bookkeeping
 extern "C" int pfslam_set_serial(pfslam_handle *h, int serial)
 {
@@ -2353,8 +2388,10 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
     case 8: *ptr = h->start; *bytes = 16; break;
     case 9: *ptr = h->pose; *bytes = 16; break;
     case 10: *ptr = h->gw; *bytes = (size_t)h->world * h->stride * 4; break;
-    case 14: *ptr = h->pack; *bytes = 32; break;
-    case 15: *ptr = h->packs; *bytes = (size_t)32 * h->world; break;
+    // this rank's record of the frame being enqueued = its packed {max key, negated-min key}, straight from the reduce: query it after
+    // pfslam_shard_score of the same frame (round-5 frames keep two of them, by ticket parity); 15 = every rank's record
+    case 14: *ptr = (h->shard_v2 && h->fstats) ? (void *)(h->fstats + 4 * (h->cur_seq & 1)) : (void *)h->stats; *bytes = 16; break;
+    case 15: *ptr = h->gkeys; *bytes = (size_t)16 * h->world; break;
     case 16: *ptr = h->pblk; *bytes = (size_t)3 * h->stride * 4; break;
     case 17: *ptr = h->gpose; *bytes = (size_t)h->world * 3 * h->stride * 4; break;
     // the map as the device holds it (pfslam_shard_balance_*: broadcast from the rank that re-balanced): kd_capacity entries each
@@ -2370,5 +2407,9 @@ extern "C" int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t
 
 static bool frame_v2_ok(pfslam_handle *h, int *chunks_out, int *bpc_out);                  // pfslam_frame.hip.inc
 static int frame_v2(pfslam_handle *h, int frame, const float *scan_host, int used, int bpc); // (the round-5 frame of pfslam_step)
+static int frame_v2_begin(pfslam_handle *h, int frame, const float *scan_host, int used, int bpc, bool sharded); // ... in four parts: the sharded frame's cuts
+static int frame_v2_score(pfslam_handle *h);
+static int frame_v2_chain(pfslam_handle *h);
+static int frame_v2_finish(pfslam_handle *h);
 #include "pfslam_stages.hip.inc"
 #include "pfslam_frame.hip.inc"

@@ -1,7 +1,7 @@
 // pfslam_mgpu.cpp -- multi-GPU driver in C++ on librccl directly: one process per GPU, particles sharded over the ranks,
 // map / scan / ICP / map update replicated, three all-gathers per frame over xGMI on a fixed schedule, no host wait per frame.
-// The protocol is the sharded frame of include/pfslam.h (pfslam_shard_disperse / score / weights / finish); the Python harness
-// gpu-icp-slam_amd/sharded.py runs the same protocol through torch.distributed.
+// The frame loop is libpfslam_mgpu.so's (include/pfslam_mgpu.h, host/pfslam_mgpu_lib.cpp: the sharded frame of include/pfslam.h with
+// its all-gathers launched straight into the frame's own streams); bench.py --gpus N steps its ranks through the same library.
 //
 //   pfslam_mgpu --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX]
 //               [--global-particles G] [--topology 1|2]
@@ -16,7 +16,6 @@
 // map (PREFIX.rank<r>.particles / .nodes) for bit-comparison with a single-handle pfslam_step run.
 // --global-particles G: total particle count when it is not N x PARTICLES_PER_GPU (ragged last shard).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cstdio>
@@ -32,7 +31,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
-#include "../../include/pfslam.h"
+#include "../../include/pfslam_mgpu.h"
 
 static int g_rank = 0;
 #define PF(call)                                                                                          \
@@ -50,15 +49,6 @@ static int g_rank = 0;
             return 1;                                                                                     \
         }                                                                                                 \
     } while (0)
-#define NCCL(call)                                                                                        \
-    do {                                                                                                  \
-        ncclResult_t r__ = (call);                                                                        \
-        if (r__ != ncclSuccess) {                                                                         \
-            fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, ncclGetErrorString(r__));                \
-            return 1;                                                                                     \
-        }                                                                                                 \
-    } while (0)
-
 static std::vector<char> slurp(const char *path)
 {
     std::ifstream f(path, std::ios::binary);
@@ -153,15 +143,18 @@ static int launch(int argc, char **argv, const Args &a)
 }
 
 // ---- one rank ---------------------------------------------------------------------------------------------------------
-static int get_id(int rank, const std::string &path, ncclUniqueId &id)
+static int get_id(int rank, const std::string &path, unsigned char id[PFSLAM_MGPU_ID_BYTES])
 {
     if (rank == 0) {
-        NCCL(ncclGetUniqueId(&id));
+        if (pfslam_mgpu_make_id(id)) {
+            fprintf(stderr, "[rank 0] %s\n", pfslam_mgpu_last_error());
+            return 1;
+        }
         unlink(path.c_str()); // an id left behind by a run that died (a clean run removes its own, see run_rank)
         const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
         const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
         FILE *f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
-        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) {
+        if (!f || fwrite(id, PFSLAM_MGPU_ID_BYTES, 1, f) != 1) {
             fprintf(stderr, "cannot write %s\n", tmp.c_str());
             return 1;
         }
@@ -174,9 +167,9 @@ static int get_id(int rank, const std::string &path, ncclUniqueId &id)
     }
     for (int tries = 0; tries < 6000; tries++) { // up to 60 s
         struct stat st;
-        if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id) && st.st_uid == getuid()) {
+        if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)PFSLAM_MGPU_ID_BYTES && st.st_uid == getuid()) {
             FILE *f = fopen(path.c_str(), "rb");
-            if (f && fread(&id, sizeof(id), 1, f) == 1) {
+            if (f && fread(id, PFSLAM_MGPU_ID_BYTES, 1, f) == 1) {
                 fclose(f);
                 return 0;
             }
@@ -184,104 +177,17 @@ static int get_id(int rank, const std::string &path, ncclUniqueId &id)
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(10));
     }
-    fprintf(stderr, "[rank %d] no ncclUniqueId in %s after 60 s\n", rank, path.c_str());
+    fprintf(stderr, "[rank %d] no job id in %s after 60 s\n", rank, path.c_str());
     return 1;
 }
 
-struct Buffers { // device pointers of the handle's exchange buffers (pfslam_device_ptr)
-    void *pack, *packs, *w, *gw, *pose_blk, *gpose;
-};
-static int query(pfslam_handle *h, Buffers &b)
-{
-    size_t bytes;
-    PF(pfslam_device_ptr(h, 14, &b.pack, &bytes));
-    PF(pfslam_device_ptr(h, 15, &b.packs, &bytes));
-    PF(pfslam_device_ptr(h, 5, &b.w, &bytes));
-    PF(pfslam_device_ptr(h, 10, &b.gw, &bytes));
-    PF(pfslam_device_ptr(h, 16, &b.pose_blk, &bytes)); // alternates between two allocations with every frame
-    PF(pfslam_device_ptr(h, 17, &b.gpose, &bytes));
-    return 0;
-}
-
-struct Rank {
-    pfslam_handle *h = nullptr;
-    ncclComm_t comm = nullptr;
-    hipStream_t stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_p = nullptr, ev_pg = nullptr, ev_w = nullptr, ev_wg = nullptr;
-    int stride = 0, world = 1, collectives = 0, balance_builds = 0, balance_broadcasts = 0;
-};
-
-// the sharded frame of include/pfslam.h: three all-gathers on a fixed schedule, NO host wait (the frame is booked one step
-// later from its pinned header, like pfslam_step's)
-static int step(Rank &R, int frame, const float *scan)
-{
-    if (R.world > 1) { // KDTree::Balance (frame % 100 == 5) ONCE per node: rank 0 builds, the others take its device arrays (28 B per node)
-        int due = 0, n_nodes = 0;
-        PF(pfslam_shard_balance_due(R.h, frame, &due, &n_nodes));
-        if (due) {
-            if (g_rank == 0) {
-                PF(pfslam_shard_balance_build(R.h, frame));
-                R.balance_builds++;
-            }
-            static const int ids[5] = {20, 21, 22, 23, 24};
-            const size_t per_node[5] = {16, 4, 4, 4, 0};
-            for (int k = 0; k < 5; k++) {
-                void *p = nullptr;
-                size_t bytes = 0;
-                PF(pfslam_device_ptr(R.h, ids[k], &p, &bytes));
-                const size_t count = k < 4 ? per_node[k] * (size_t)n_nodes : 16;
-                NCCL(ncclBroadcast(p, p, count, ncclChar, 0, R.comm, R.stream));
-            }
-            if (g_rank != 0) PF(pfslam_shard_balance_adopt(R.h));
-            R.balance_broadcasts++;
-        }
-    }
-    int seeded = 0;
-    PF(pfslam_shard_disperse(R.h, frame, scan, &seeded));
-    if (seeded) return 0; // the first scan only seeds the (replicated) map
-    Buffers b;
-    if (query(R.h, b)) return 1;
-    const bool comm = R.world > 1; // world 1: buffers 10 / 17 alias 5 / 16, nothing to move
-    // the poses are final right after the dispersion: gather [x | y | theta] on the side stream, under the score kernel
-    if (comm) {
-        HIP(hipEventRecord(R.ev_p, R.stream));
-        HIP(hipStreamWaitEvent(R.comm_stream, R.ev_p, 0));
-        NCCL(ncclAllGather(b.pose_blk, b.gpose, (size_t)3 * R.stride, ncclFloat, R.comm, R.comm_stream));
-        HIP(hipEventRecord(R.ev_pg, R.comm_stream));
-    }
-    PF(pfslam_shard_score(R.h));
-    if (comm) {
-        NCCL(ncclAllGather(b.pack, b.packs, 32, ncclChar, R.comm, R.stream)); // keys + pose of every shard's best particle
-    } else {
-        HIP(hipMemcpyAsync(b.packs, b.pack, 32, hipMemcpyDeviceToDevice, R.stream));
-    }
-    PF(pfslam_shard_weights(R.h));
-    // the weights are final: gather them on the side stream while the replicated map update's lists are built
-    if (comm) {
-        HIP(hipEventRecord(R.ev_w, R.stream));
-        HIP(hipStreamWaitEvent(R.comm_stream, R.ev_w, 0));
-        NCCL(ncclAllGather(b.w, b.gw, (size_t)R.stride, ncclFloat, R.comm, R.comm_stream));
-        HIP(hipEventRecord(R.ev_wg, R.comm_stream));
-        HIP(hipStreamWaitEvent(R.stream, R.ev_pg, 0));
-        HIP(hipStreamWaitEvent(R.stream, R.ev_wg, 0));
-    }
-    PF(pfslam_shard_finish(R.h));
-    R.collectives += 3;
-    return 0;
-}
-
-static int barrier(Rank &R, double *max_inout, double *scratch_dev)
-{
-    // all-reduce MAX of one double: a barrier, and the max-over-ranks of the elapsed time when asked for
-    double v = max_inout ? *max_inout : 0.0;
-    HIP(hipMemcpyAsync(scratch_dev, &v, 8, hipMemcpyHostToDevice, R.stream));
-    NCCL(ncclAllReduce(scratch_dev, scratch_dev, 1, ncclDouble, ncclMax, R.comm, R.stream));
-    HIP(hipMemcpyAsync(&v, scratch_dev, 8, hipMemcpyDeviceToHost, R.stream));
-    HIP(hipStreamSynchronize(R.stream));
-    HIP(hipStreamSynchronize(R.comm_stream));
-    if (max_inout) *max_inout = v;
-    return 0;
-}
+#define MG(call)                                                                                          \
+    do {                                                                                                  \
+        if (call) {                                                                                       \
+            fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, pfslam_mgpu_last_error());               \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
 
 static int run_rank(const Args &a, int rank, int world, int local_rank, const std::string &id_file)
 {
@@ -311,19 +217,9 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
         }
     }
     HIP(hipSetDevice(local_rank));
-    ncclUniqueId id;
-    if (get_id(rank, id_file, id)) return 1;
-    Rank R;
-    NCCL(ncclCommInitRank(&R.comm, world, id, rank));
-    if (rank == 0) unlink(id_file.c_str()); // every rank has joined: a later run must never pick this id up
-    HIP(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
-    HIP(hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
-    HIP(hipEventCreateWithFlags(&R.ev_p, hipEventDisableTiming));
-    HIP(hipEventCreateWithFlags(&R.ev_pg, hipEventDisableTiming));
-    HIP(hipEventCreateWithFlags(&R.ev_w, hipEventDisableTiming));
-    HIP(hipEventCreateWithFlags(&R.ev_wg, hipEventDisableTiming));
-    R.stride = stride;
-    R.world = world;
+    unsigned char id[PFSLAM_MGPU_ID_BYTES];
+    memset(id, 0, sizeof(id));
+    if (world > 1 && get_id(rank, id_file, id)) return 1;
     pfslam_config cfg;
     pfslam_default_config(&cfg);
     cfg.n_particles = count;
@@ -332,38 +228,39 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
     cfg.global_offset = (int)off;
     cfg.global_n = (int)G;
     cfg.shard_stride = stride;
-    PF(pfslam_create(&cfg, &R.h));
-    PF(pfslam_set_stream(R.h, R.stream));
-    if (world > 1) PF(pfslam_set_shard_balance(R.h, 1));
-    if (a.topology) PF(pfslam_set_topology(R.h, a.topology)); // replicated: every rank keeps the same graph, nothing is exchanged for it
-    PF(pfslam_set_map(R.h, reinterpret_cast<const pfslam_node *>(map.data()), n_nodes));
-    double *scratch = nullptr;
-    HIP(hipMalloc((void **)&scratch, 8));
+    pfslam_handle *h = nullptr;
+    PF(pfslam_create(&cfg, &h));
+    pfslam_mgpu *M = nullptr;
+    MG(pfslam_mgpu_create(world > 1 ? id : nullptr, world, rank, h, &M));
+    if (rank == 0 && world > 1) unlink(id_file.c_str()); // every rank has joined: a later run must never pick this id up
+    if (a.topology) PF(pfslam_set_topology(h, a.topology)); // replicated: every rank keeps the same graph, nothing is exchanged for it
+    PF(pfslam_set_map(h, reinterpret_cast<const pfslam_node *>(map.data()), n_nodes));
     const float *s = reinterpret_cast<const float *>(scans.data());
-    for (int f = 1; f <= 5; f++) PF(pfslam_motion_update(R.h, f)); // same dispersed starting cloud as bench.py
+    for (int f = 1; f <= 5; f++) PF(pfslam_motion_update(h, f)); // same dispersed starting cloud as bench.py
     int frame = a.first_frame, k = 0;
-    for (int i = 0; i < a.warmup; i++, k++)
-        if (step(R, frame++, s + (size_t)(k % n_frames) * beams)) return 1;
-    if (barrier(R, nullptr, scratch)) return 1;
+    for (int i = 0; i < a.warmup; i++, k++) MG(pfslam_mgpu_step(M, frame++, s + (size_t)(k % n_frames) * beams));
+    MG(pfslam_mgpu_barrier_max(M, nullptr));
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < a.steps; i++, k++)
-        if (step(R, frame++, s + (size_t)(k % n_frames) * beams)) return 1;
-    if (barrier(R, nullptr, scratch)) return 1;
+    for (int i = 0; i < a.steps; i++, k++) MG(pfslam_mgpu_step(M, frame++, s + (size_t)(k % n_frames) * beams));
+    MG(pfslam_mgpu_barrier_max(M, nullptr));
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (barrier(R, &sec, scratch)) return 1; // MAX over the ranks
+    MG(pfslam_mgpu_barrier_max(M, &sec)); // MAX over the ranks
     float pose[3];
-    PF(pfslam_get_pose(R.h, pose));
+    PF(pfslam_get_pose(h, pose));
+    int mode[4] = {0, 0, 0, 0};
+    PF(pfslam_frame_mode(h, mode));
     // topology: the loop-closure proposals of the last frame and the graph, which must be the same on every rank (checked: MAX == MIN of a digest)
     int n_closures = 0, n_topo = 0, topo_idx = 0;
     if (a.topology) {
-        PF(pfslam_get_closures(R.h, nullptr, 0, &n_closures));
+        PF(pfslam_get_closures(h, nullptr, 0, &n_closures));
         std::vector<float> nodes(3 * 4096);
-        PF(pfslam_get_topology(R.h, nodes.data(), 4096, &n_topo, &topo_idx));
+        PF(pfslam_get_topology(h, nodes.data(), 4096, &n_topo, &topo_idx));
         double digest = 0.0;
         for (int k = 0; k < 3 * std::min(n_topo, 4096); k++) digest = digest * 1.000001 + (double)nodes[k];
         digest += 1e6 * n_closures + 1e3 * topo_idx + n_topo;
         double hi = digest, lo = -digest;
-        if (barrier(R, &hi, scratch) || barrier(R, &lo, scratch)) return 1;
+        MG(pfslam_mgpu_barrier_max(M, &hi));
+        MG(pfslam_mgpu_barrier_max(M, &lo));
         if (hi != -lo) {
             fprintf(stderr, "[rank %d] the ranks' topology graphs differ\n", rank);
             return 3;
@@ -373,25 +270,27 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
         const pfslam_particle *p;
         const pfslam_node *nd;
         int np = 0, nn = 0;
-        PF(pfslam_get_particles(R.h, &p, &np));
+        PF(pfslam_get_particles(h, &p, &np));
         std::ofstream(a.dump + ".rank" + std::to_string(rank) + ".particles", std::ios::binary).write((const char *)p, (size_t)np * sizeof(*p));
-        PF(pfslam_get_map(R.h, &nd, &nn));
+        PF(pfslam_get_map(h, &nd, &nn));
         std::ofstream(a.dump + ".rank" + std::to_string(rank) + ".nodes", std::ios::binary).write((const char *)nd, (size_t)nn * sizeof(*nd));
     }
+    int st[4] = {0, 0, 0, 0};
+    MG(pfslam_mgpu_stats(M, st));
     if (rank == 0) {
         printf("{\"metric\": \"particle-scan evals/sec (1081 beams x N particles), full particleFilter step, KD path\", \"value\": %.6e, "
                "\"unit\": \"particle-scan evals/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.6f, "
                "\"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, \"dtype\": \"f32\", \"data\": \"synthetic\", "
                "\"config\": {\"workload\": \"1081-beam scans, %d particles/GPU, %d-point KD map, full SLAM step\", \"particles_global\": %ld, "
                "\"parallelism\": \"particles sharded x%d, map replicated\", \"kd_size_end\": %d, \"driver\": \"C++ / librccl (host/pfslam_mgpu.cpp)\", "
-               "\"collectives\": %d, \"topology\": {\"mode\": %d, \"nodes\": %d, \"node\": %d, \"closures_last_frame\": %d}, \"pose\": [%.9g, %.9g, %.9g]}}\n",
-               (double)G * a.steps / sec, world, a.steps, a.warmup, sec / a.steps * 1e3, stride, n_nodes, G, world, pfslam_kd_size(R.h),
-               R.collectives, a.topology, n_topo, topo_idx, n_closures, pose[0], pose[1], pose[2]);
+               "\"collectives\": %d, \"frame\": {\"round5\": %d, \"edges\": \"%s\", \"one_stream\": %d}, "
+               "\"topology\": {\"mode\": %d, \"nodes\": %d, \"node\": %d, \"closures_last_frame\": %d}, \"pose\": [%.9g, %.9g, %.9g]}}\n",
+               (double)G * a.steps / sec, world, a.steps, a.warmup, sec / a.steps * 1e3, stride, n_nodes, G, world, pfslam_kd_size(h),
+               st[0], mode[0], mode[1] ? "gates" : "events", mode[2], a.topology, n_topo, topo_idx, n_closures, pose[0], pose[1], pose[2]);
         fflush(stdout);
     }
-    PF(pfslam_destroy(R.h));
-    (void)hipFree(scratch);
-    NCCL(ncclCommDestroy(R.comm));
+    MG(pfslam_mgpu_destroy(M));
+    PF(pfslam_destroy(h));
     return 0;
 }
 
@@ -404,7 +303,13 @@ int main(int argc, char **argv)
         return 1;
     }
     const char *rk = env_any("PFSLAM_RANK", "RANK");
-    if (!rk) return launch(argc, argv, a);
+    if (!rk) {
+        if (a.gpus == 1) { // one rank: no children, no job id
+            setenv("PFSLAM_RANK", "0", 1);
+            return run_rank(a, 0, 1, 0, "");
+        }
+        return launch(argc, argv, a);
+    }
     const char *ws = env_any("PFSLAM_WORLD", "WORLD_SIZE"), *lr = env_any("PFSLAM_LOCAL_RANK", "LOCAL_RANK");
     const int rank = atoi(rk), world = ws ? atoi(ws) : 1, local_rank = lr ? atoi(lr) : rank;
     std::string id_file = getenv("PFSLAM_ID_FILE") ? getenv("PFSLAM_ID_FILE") : "";

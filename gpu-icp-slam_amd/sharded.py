@@ -1,18 +1,21 @@
 """Multi-GPU stepping: particles shard over the ranks of one node (one process per GPU), the map, the scan,
-the ICP solve and the map update are replicated, and the merges are three all-gathers per frame on a FIXED schedule
-(torch.distributed: backend "nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).  The C++ driver
-host/pfslam_mgpu.cpp runs the same protocol on librccl directly.
+the ICP solve and the map update are replicated, and the merges are three all-gathers per frame on a FIXED schedule.
+
+Production (bench.py --gpus N, host/pfslam_mgpu.cpp): `native` = pkg.MgpuRank -- libpfslam_mgpu.so steps the rank, its RCCL
+all-gathers launched straight into the frame's own streams (include/pfslam_mgpu.h).  Without it (the CPU tests under gloo, the
+one-GPU gloo test) the same protocol runs through torch.distributed, each collective issued with the stream pfslam_shard_stream
+names as torch's current stream.
 
 Per frame (include/pfslam.h "multi-GPU"):
-    all-gather  of 3 stride x f32       [x | y | theta] in one piece, right after the dispersion: it runs on the collective's
-                                        own stream UNDER the score kernel
-    all-gather  of 32 B per rank        {max key, negated-min key, pose of the shard's best particle}: every rank derives the
-                                        global min / max / first-occurrence argmax and the best pose from the gathered records
-    all-gather  of stride x f32         weights -> global array (Neff, cdf and sampling run on it, replicated); overlapped
-                                        with the replicated map update
+    all-gather  of 3 stride x f32       [x | y | theta] in one piece, right after the dispersion: on the particle stream, which has
+                                        nothing else to do until the reduce -- it runs UNDER the scan-match kernel
+    all-gather  of 16 B per rank        a shard's packed {max key, negated-min key}, straight from its reduce: every rank derives the
+                                        global min / max / first-occurrence argmax, and reads the best particle's pose out of the
+                                        gathered pose blocks
+    all-gather  of stride x f32         weights -> global array (Neff, cdf and sampling run on it, replicated)
 No call waits for the device and no collective depends on data: the resample is decided ON the device (Neff of the gathered
 weights), its sources are read from the gathered pose blocks, and the frame is booked one step later from its pinned header --
-the sharded frame is the single-GPU pipeline of pfslam_step with three collectives placed in it.
+the sharded frame IS the single-GPU frame of pfslam_step, in four parts with three collectives between them.
 Rank r owns the global particles [r * stride, min((r + 1) * stride, N)), stride = ceil(N / world): the last shard may be
 shorter, the exchange buffers are padded to `stride`.  Everything that touches randomness is keyed by GLOBAL particle
 indices, and every sum runs on the global array in the canonical order, so the result is bit-identical for any number of
@@ -59,11 +62,15 @@ class GpuBuffers:
             return t
 
         self.stats = view(0, "<i8", 8, torch.int64)
-        self.pack = view(14, "<i8", 8, torch.int64)     # this rank's 32-byte record
-        self.packs = view(15, "<i8", 8, torch.int64)    # world x 32 bytes
+        self.packs = view(15, "<i8", 8, torch.int64)    # world x 16 bytes: every rank's packed keys
         self.w = view(5, "<f4", 4, torch.float32)       # stride floats (padded)
         self.gw = view(10, "<f4", 4, torch.float32)     # world x stride
         self.eng, self._view = eng, view
+
+    @property
+    def pack(self):
+        # this rank's 16-byte record (its packed max / negated-min keys) alternates between two addresses: ask after shard_score
+        return self._view(14, "<i8", 8, self.torch.int64)
 
     def pose_blocks(self):
         # the local block [x | y | theta] swaps buffers on every resample, so re-query the pointer
@@ -80,27 +87,27 @@ class GpuBuffers:
 
 
 class ShardedSlam:
-    def __init__(self, pkg, n_global, rank, world, device=0, dist=None, torch=None, engine=None, buffers=None, **kw):
+    def __init__(self, pkg, n_global, rank, world, device=0, dist=None, torch=None, engine=None, buffers=None, native_id=None, native=False, **kw):
         self.n_global, self.rank, self.world = n_global, rank, world
         self.stride, self.goff, self.n = shard_layout(n_global, world, rank)
         shard_layout(n_global, world, world - 1)  # the last rank must not be empty
         self.dist, self.torch = dist, torch
+        self.native = None
+        self._ext = {}
         if engine is None:
             engine = pkg.PfSlam(self.n, device=device, global_offset=self.goff, global_n=n_global, shard_stride=self.stride, **kw)
+            if native or native_id is not None:
+                # libpfslam_mgpu.so steps the rank: RCCL all-gathers launched straight into the frame's own streams
+                self.native = pkg.MgpuRank(engine, world, rank, native_id)
             if torch is not None:
-                # run the kernels on torch's current stream so RCCL collectives and kernels are stream-ordered; a stream of
-                # our own rather than the legacy null stream, which synchronises implicitly with every blocking stream
-                if torch.cuda.current_stream().cuda_stream == 0:
-                    self._stream = torch.cuda.Stream(device=device)
-                    torch.cuda.set_stream(self._stream)
-                engine.set_stream(torch.cuda.current_stream().cuda_stream)
-            buffers = GpuBuffers(engine, torch, device)
+                buffers = GpuBuffers(engine, torch, device)
         self.eng, self.buf = engine, buffers
+        self.device = device
         self.collectives = 0   # all-gathers issued: 3 in every frame (fixed schedule)
         # KDTree::Balance (frame % 100 == 5) ONCE per node: rank 0 builds, the others receive the device arrays (28 B per node)
         self.balance_builds = 0      # host builds this rank ran
         self.balance_broadcasts = 0  # re-balances this rank took part in
-        if world > 1:
+        if world > 1 and self.native is None:
             engine.set_shard_balance(True)
 
     # -- pass-throughs
@@ -133,18 +140,28 @@ class ShardedSlam:
         self.eng.set_particles(np.ascontiguousarray(p_global[self.goff:self.goff + self.n]))
     def particles(self): return self.eng.particles()   # this rank's shard
 
-    def _all_gather(self, dst, src, async_op=False):
-        """Returns a work handle when async_op (wait() it before the result is used), else None."""
+    def _all_gather(self, dst, src, which):
+        """Collective `which` (0 pose blocks, 1 keys, 2 weights) of the frame being enqueued, in the stream the engine names for it
+        (GPU engines: pfslam_shard_stream -- stream order is all the ordering there is; gloo completes it before it returns)."""
         self.collectives += 1
         if self.world == 1:
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
-            return None
-        return self.dist.all_gather_into_tensor(dst, src, async_op=async_op) if async_op else \
+            return
+        st = self.eng.shard_stream(which) if hasattr(self.eng, "shard_stream") else None
+        if st is None or self.torch is None or not src.is_cuda:
+            self.dist.all_gather_into_tensor(dst, src)
+            return
+        ext = self._ext.get(st)
+        if ext is None:
+            ext = self._ext[st] = self.torch.cuda.ExternalStream(st, device=self.torch.device("cuda", self.device))
+        with self.torch.cuda.stream(ext):
             self.dist.all_gather_into_tensor(dst, src)
 
     def step(self, frame, scan):
         """One frame, enqueued: nothing here waits for the device (see include/pfslam.h, pfslam_shard_*)."""
+        if self.native is not None:
+            self.native.step(frame, scan)
+            self.collectives += 3
+            return
         e, b = self.eng, self.buf
         if self.world > 1:
             due, n_nodes = e.shard_balance_due(frame)   # the same answer on every rank: frame number and (replicated) map size
@@ -159,21 +176,21 @@ class ShardedSlam:
                 self.balance_broadcasts += 1
         if e.shard_disperse(frame, scan):       # first scan seeds the map (kernel.cu:1714-1717); replicated
             return
-        if self.world == 1:                     # buffers 10 / 17 alias 5 / 16: only the record moves (to its gathered slot)
+        if self.world == 1:                     # buffers 10 / 17 alias 5 / 16, nothing reads buffer 15: no collective at all
             self.collectives += 3
             e.shard_score()
-            b.packs.copy_(b.pack)
             e.shard_weights()
             e.shard_finish()
             return
         local, glob = b.pose_blocks()           # the local block alternates between two allocations: ask every frame
-        # the poses are final: gather them now; the collective runs on its own stream under the score kernel
-        p_pose = self._all_gather(glob, local, async_op=True)
-        e.shard_score()                         # lane order, cell rows, scan-match, reduce -> this shard's 32-byte record
-        self._all_gather(b.packs, b.pack)       # 32 bytes per rank: keys + pose of every shard's best particle
-        e.shard_weights()                       # global min / max / argmax, weights, pose = best + ICP increment; map lists start
-        p_w = self._all_gather(b.gw, b.w, async_op=True)   # the weights are final: gathered under the map update
-        for p in (p_pose, p_w):
-            if p is not None:
-                p.wait()                        # stream-level: orders the compute stream behind the collective
-        e.shard_finish()                        # Neff on the global weights, insert + header, gated resample, booking
+        self._all_gather(glob, local, 0)        # the poses are final: gathered on the particle stream, under the scan-match kernel
+        e.shard_score()                         # scan-match, reduce -> this shard's packed keys
+        self._all_gather(b.packs, b.pack, 1)    # 16 bytes per rank, on the chain stream between the reduce and the walls
+        e.shard_weights()                       # global min / max / argmax, pose = best + ICP increment, walls + insert; this shard's weights
+        self._all_gather(b.gw, b.w, 2)          # the weights are final
+        e.shard_finish()                        # Neff on the global weights, header, gated resample; the free cells' chain; booking
+
+    def close(self):
+        if self.native is not None:
+            self.native.close()
+            self.native = None

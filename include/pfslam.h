@@ -194,31 +194,33 @@ int pfslam_kd_size(pfslam_handle *h);
  * The sharded frame.  Like pfslam_step it is only ENQUEUED: no call waits for the device, the frame is booked one step later
  * from its pinned header, and the schedule of the caller's collectives is FIXED -- three all-gathers in every frame, none of
  * them data-dependent (the resample is decided on the device, on the gathered weights, and reads its sources from the gathered
- * pose blocks):
- *   pfslam_shard_disperse   scan upload, re-balance if due, ICP fork, dispersion of this shard.  *seeded = 1 when the frame only
- *                           seeded the map (first scan): nothing else to do for this frame.
- *   [all-gather buffer 16 -> buffer 17]   pose blocks [x | y | theta] in ONE piece of 3 * shard_stride floats per rank.  They are
- *                           final right after the dispersion, so the caller issues this on a SIDE stream (ordered behind the
- *                           handle's stream by an event) and it runs UNDER the score kernel
- *   pfslam_shard_score      lane order, plan, scan-match, reduce -> this rank's 32-byte record in buffer 14:
- *                           {int64 max key, int64 negated-min key, float x, y, theta, 0} of the shard's best particle;
- *                           key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index)
- *   [all-gather buffer 14 -> buffer 15]   32 bytes per rank, on the handle's stream
- *   pfslam_shard_weights    global min / max / first argmax from the gathered records, weight update of this shard, pose =
- *                           best particle + increment of the ICP solve (which ran under the score kernel); the replicated map
- *                           update's rays, cell lists and list traversal start on the handle's aux stream
- *   [all-gather buffer 5 -> buffer 10]    weights, shard_stride floats per rank, side stream, under the map update
- *   pfslam_shard_finish     the caller first makes the handle's stream wait for BOTH side-stream all-gathers (event waits, no host
- *                           wait); then: sums + Neff on the gathered weights, insert of the new walls + frame header, gated
- *                           resample (sources from buffer 17), booking of the frame `lag` steps back
- * Results are bit-identical for any number of ranks.  Buffer 16 alternates between two allocations with every frame (the resample
- * kernel always moves the particles to the other block): query it after pfslam_shard_disperse of the same frame.
+ * pose blocks).  The four calls are the four parts of the very frame pfslam_step enqueues, and every collective goes straight into
+ * one of that frame's streams -- pfslam_shard_stream names it; stream order is all the ordering the caller has to provide (no event,
+ * no stream of the caller's own: launch the collective with that stream as its stream argument):
+ *   pfslam_shard_disperse   scan upload, re-balance if due; dispersion and lane order of this shard; the cells' passes; the ICP solve.
+ *                           *seeded = 1 when the frame only seeded the map (first scan): nothing else to do for this frame.
+ *   [all-gather buffer 16 -> buffer 17, stream 0]   pose blocks [x | y | theta] in ONE piece of 3 * shard_stride floats per rank.  They
+ *                           are final right after the dispersion; the stream has nothing else to do until the reduce, so the
+ *                           collective runs UNDER the scan-match kernel
+ *   pfslam_shard_score      scan-match, reduce -> this rank's 16-byte record in buffer 14: its packed {int64 max key, int64 negated-min
+ *                           key}; key = (orderable_u32(fit) << 32) | (0xFFFFFFFF - global_index)
+ *   [all-gather buffer 14 -> buffer 15, stream 1]   16 bytes per rank: the one collective on the frame's critical chain
+ *   pfslam_shard_weights    global min / max / first argmax from the gathered keys; the best particle's pose is read out of the gathered
+ *                           pose blocks; pose = best particle + increment of the ICP solve; walls at that pose, insert, cell rows;
+ *                           weight update of this shard
+ *   [all-gather buffer 5 -> buffer 10, stream 0]    weights, shard_stride floats per rank
+ *   pfslam_shard_finish     sums + Neff on the gathered weights, frame header, gated resample (sources from buffer 17); the free
+ *                           cells' chain of the replicated map update; booking of the frame `lag` steps back
+ * Results are bit-identical for any number of ranks.  Buffers 14 and 16 alternate between two allocations from frame to frame: query
+ * 16 after pfslam_shard_disperse, 14 after pfslam_shard_score of the same frame.
  * A handle that holds ALL particles (global_n == n_particles) may be driven through the same calls (world 1): buffers 10 / 17
- * then alias 5 / 16 and the all-gathers of weights and pose blocks are no-ops for the caller to skip. */
+ * then alias 5 / 16, nothing reads buffer 15, and there is no collective to issue. */
 int pfslam_shard_disperse(pfslam_handle *h, int frame, const float *scan_host, int *seeded);
 int pfslam_shard_score(pfslam_handle *h);
 int pfslam_shard_weights(pfslam_handle *h);
 int pfslam_shard_finish(pfslam_handle *h);
+/* the stream collective `which` (0 pose blocks, 1 keys, 2 weights) of the frame being enqueued is to be issued on: a hipStream_t */
+int pfslam_shard_stream(pfslam_handle *h, int which, void **hip_stream);
 /* Multi-GPU re-balance, ONE host build per node (the ranks hold identical maps): after pfslam_set_shard_balance(h, 1) the sharded
  * frame does not re-balance by itself.  In front of pfslam_shard_disperse every rank calls pfslam_shard_balance_due (books the frames
  * in flight when the period hits; *n_nodes = map size).  If due: the root rank calls pfslam_shard_balance_build (KDTree::Balance,
@@ -238,7 +240,7 @@ int pfslam_measurement_apply(pfslam_handle *h, int *best_global, float *fmin, fl
  * which: 0 stats (8 x i64), 1 fit (n x f32), 2 x, 3 y, 4 theta (n x f32 each; inside buffer 16), 5 w (shard_stride x f32, the
  *        first n valid), 6 weight tile sums, 7 scan (n_beams x f32), 8 best-particle pose (4 x f32), 9 robot pose (4 x f32),
  *        10 global w (world * shard_stride x f32, rank-major, the first global_n valid; aliases 5 when unsharded),
- *        14 this rank's 32-byte measurement record, 15 the gathered records (world x 32 B),
+ *        14 this rank's 16-byte measurement record (its packed max / negated-min keys), 15 the gathered records (world x 16 B),
  *        16 local pose block [x | y | theta] (3 * shard_stride x f32; moves when a resample swaps the double buffer),
  *        17 global pose blocks (world x 3 * shard_stride x f32, rank-major; aliases 16 when unsharded) */
 int pfslam_device_ptr(pfslam_handle *h, int which, void **ptr, size_t *bytes);
@@ -294,6 +296,12 @@ int pfslam_cell_stats(pfslam_handle *h, double out[16]);
  * weights) over `iters` launches each, HIP events on the handle's stream */
 int pfslam_time_score_grid(pfslam_handle *h, int iters, float *ms_kernel, float *ms_pass);
 int pfslam_set_variant(pfslam_handle *h, int variant);
+/* Transcendentals.  0 (default) = the specification of csrc/pf_math.h: fixed sequences of IEEE double operations rounded once, which the
+ * CPU oracle follows bit for bit.  1 = the device library's cosf / sinf in CleanLidarScan (kernel.cu:182-187) and erfcinvf in the
+ * dispersion (kernel.cu:375-397) -- what the reference's own text compiles to on this platform: with it the product's kernels equal the
+ * reference's kernels built for gfx950 with zero mismatches (tests/test_gpu_ref_kernels.py); results then differ from the oracle's in
+ * the last place of an end point now and then. */
+int pfslam_set_trig(pfslam_handle *h, int devlib);
 /* ---- round-5 frame loop: test and measurement support (no reference counterpart) ----
  * pfslam_set_serial(h, 1): every launch of every frame on ONE stream, in the order the four chains of a frame are enqueued (what the
  * environment variable PFSLAM_SERIAL=1 sets at creation).  Results and the cell rows' bookkeeping are the same as with the chains on their

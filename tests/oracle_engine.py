@@ -83,11 +83,13 @@ class OracleShardEngine:
         self.x, self.y, self.th = self.pblk[0:n], self.pblk[S:S + n], self.pblk[2 * S:2 * S + n]
         self.w_pad = z(S); self.w = self.w_pad[:n]; self.w[:] = 1
         self.wm = np.ones(n, np.float32)
-        self.gw_pad = z(self.world * S); self.gw = self.gw_pad[:gn]
-        self.gpose = z(self.world * 3 * S)
+        # (a one-rank job: the global views alias the local arrays, as buffers 10 / 17 alias 5 / 16 on the GPU handle)
+        self.gw_pad = z(self.world * S) if self.world > 1 else self.w_pad
+        self.gw = self.gw_pad[:gn]
+        self.gpose = z(self.world * 3 * S) if self.world > 1 else self.pblk
         self.stats = np.zeros(8, np.int64)
-        self.pack = np.zeros(4, np.int64)            # {kmax, kmin, (x, y) bits, (theta, 0) bits}
-        self.packs = np.zeros(4 * self.world, np.int64)
+        self.pack = np.zeros(2, np.int64)            # this shard's packed {kmax, kmin}
+        self.packs = np.zeros(2 * self.world, np.int64)
         self.start = z(4)
         self.tree = np.zeros(kd_capacity, O.NODE_DTYPE)
         self.size = 0
@@ -208,19 +210,20 @@ class OracleShardEngine:
         return False
 
     def shard_score(self):
-        """pfslam_shard_score: scan-match of this shard, its packed min / max keys and the pose of its best particle."""
+        """pfslam_shard_score: scan-match of this shard -> its packed min / max keys (the 16-byte record)."""
         self.score_kd(fetch=False)
         self.measurement_local()
-        lb = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF)) - self.goff
         self.pack[0], self.pack[1] = self.stats[0], self.stats[1]
-        self.pack[2:].view(np.float32)[:] = (self.x[lb], self.y[lb], self.th[lb], 0.0)
 
     def shard_weights(self):
         """pfslam_shard_weights: merge the gathered records, weights, pose = best particle + ICP increment."""
-        rec = self.packs.reshape(self.world, 4)
-        owner = int(np.argmax(rec[:, 0]))            # first occurrence of the maximum key
-        self.stats[0], self.stats[1] = rec[owner, 0], rec[:, 1].max()
-        self.start[:] = rec[owner, 2:].copy().view(np.float32)
+        rec = self.packs.reshape(self.world, 2)
+        self.stats[0], self.stats[1] = rec[:, 0].max(), rec[:, 1].max()
+        g = int(0xFFFFFFFF - (int(self.stats[0]) & 0xFFFFFFFF))   # the job's best particle: its pose out of the gathered pose blocks
+        S = self.stride
+        r, j = g // S, g % S
+        blk = self.gpose[r * 3 * S:(r + 1) * 3 * S] if self.world > 1 else self.pblk
+        self.start[:3] = (blk[j], blk[S + j], blk[2 * S + j])
         best, _, _ = self._apply_weights()
         self._trace["best"] = best
         self.robot[:] = self.start[:3] + self.icp_delta

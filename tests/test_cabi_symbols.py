@@ -21,6 +21,18 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(pkg.binding.SYMBOLS) == set(names)
 
 
+def test_mgpu_library_exports_every_declared_symbol(pkg):
+    """include/pfslam_mgpu.h (the sharded frame with its all-gathers on librccl) against host/libpfslam_mgpu.so: loads without a GPU."""
+    src = open(os.path.join(ROOT, "include", "pfslam_mgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pfslam_mgpu_[a-z0-9_]+)\s*\(", src)))
+    M = pkg.load_mgpu()
+    assert len(names) == 8
+    for name in names:
+        assert hasattr(M, name), "libpfslam_mgpu.so does not export %s" % name
+    assert set(pkg.binding.MGPU_SYMBOLS) == set(names)
+
+
 def test_no_gpu_is_a_loud_error_not_a_fallback(pkg):
     if pkg.device_count() > 0:
         return  # on the GPU box this is covered by the gpu tests

@@ -24,6 +24,19 @@ pytestmark = pytest.mark.gpu
 N, NB = R.PARTICLE_COUNT, R.LIDAR_SIZE
 
 
+def report(line):
+    """The agreement numbers of this file, printed AND appended to gpurun_out/ref_kernel_agreement.txt (copied to profiles/rNN_ref_kernel_agreement.txt)."""
+    import os
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "ref_kernel_agreement.txt"), "a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture()
 def rk(pkg):
     assert pkg.device_count() > 0
@@ -175,8 +188,8 @@ def test_kernEvaluateParticlesKD(pkg, rk, small_world, fractional):
     smp = slice(0, N, 50)
     trig_same = (ex[smp].view(np.int32) == e[smp].view(np.int32)).all(axis=2).mean()
     ulp = np.abs(ex[smp].view(np.int32).astype(np.int64) - e[smp].view(np.int32).astype(np.int64))
-    print("end points identical to ROCm's cosf/sinf: %.4f (max %d ulp); scores identical: %d of %d, max |diff| %.3f"
-          % (trig_same, ulp[np.isfinite(e[smp])].max(), same.sum(), N, np.abs(mine - want).max()))
+    report("kernEvaluateParticlesKD (fractional weights %s): end points of the specification identical to ROCm's cosf/sinf: %.4f (max %d ulp); restatement's scores identical: %d of %d, max |diff| %.3f"
+           % (fractional, trig_same, ulp[np.isfinite(e[smp])].max(), same.sum(), N, np.abs(mine - want).max()))
     assert ulp[np.abs(p["theta"][smp]) < 1e4].max() <= 2, "specified cos/sin further than 2 ulp from the device library's"
     assert same.mean() >= 0.9
     assert np.abs(mine - want).max() <= 0.02 * np.abs(want).max() + 16
@@ -188,7 +201,19 @@ def test_kernEvaluateParticlesKD(pkg, rk, small_world, fractional):
     got = h.score_kd()
     h.close()
     assert (got.view(np.int32) == mine.view(np.int32)).all()
-    print("product scores identical to the reference kernel: %d of %d" % ((got.view(np.int32) == want.view(np.int32)).sum(), N))
+    report("kernEvaluateParticlesKD (fractional weights %s): product (specification) scores identical to the reference kernel: %d of %d" % (fractional, (got.view(np.int32) == want.view(np.int32)).sum(), N))
+    # the device library's trigonometry (pfslam_set_trig): the product IS the reference kernel, every particle, every bit -- the
+    # headings beyond any bound included (no specification, no guard: cosf / sinf of the float sum, as the reference's text says)
+    h = pkg.PfSlam(N)
+    h.set_trig(1)
+    h.set_map(tree)
+    h.set_particles(p)
+    h.set_scan(scan)
+    dev = h.score_kd()
+    h.close()
+    bad = int((dev.view(np.int32) != want.view(np.int32)).sum())
+    report("kernEvaluateParticlesKD (fractional weights %s): product (device-library trigonometry) scores differing from the reference kernel: %d of %d" % (fractional, bad, N))
+    assert bad == 0
 
 
 def test_traceRay(rk):
@@ -239,8 +264,8 @@ def test_kernGetWalls(pkg, rk, small_world, theta, center):
             hw[int(np.float32(wx[j] * np.float32(dim)) + wy[j])] = 1
     assert ((hf != 0) == want_f).all() and ((hw != 0) == want_w).all(), "hybrid masks differ from kernGetWalls"
     of, ow = O.get_walls(scan, center[0], center[1], theta)
-    print("restatement as a whole vs kernGetWalls: free cells differing %d of %d, wall cells differing %d of %d"
-          % (((of != 0) != want_f).sum(), want_f.sum(), ((ow != 0) != want_w).sum(), want_w.sum()))
+    report("kernGetWalls theta %.1f centre %s: restatement as a whole: free cells differing %d of %d, wall cells differing %d of %d"
+           % (theta, center, ((of != 0) != want_f).sum(), want_f.sum(), ((ow != 0) != want_w).sum(), want_w.sum()))
     assert ((ow != 0) != want_w).sum() <= 0.02 * want_w.sum() + 2  # only where cos/sin round differently at a cell edge
 
 
@@ -283,7 +308,7 @@ def test_rng_hash_engine_uniform(rk):
         g = np.array([L.orc_normal(C.byref(st3), 0.0, 0.015) for _ in range(2)], np.float32)
         nd += int((g.view(np.int32) != outf[k, 2:].view(np.int32)).sum())
         assert np.abs(g - outf[k, 2:]).max() <= 4e-9 + 1e-6 * np.abs(g).max()  # erfcinv: ROCm's device library vs the specification
-    print("normal_distribution draws differing in the last place from ROCm's erfcinv: %d of %d" % (nd, 2 * n))
+    report("normal_distribution draws of the specification differing in the last place from ROCm's erfcinv: %d of %d" % (nd, 2 * n))
 
 
 def test_kernAddNoise(rk):
@@ -296,7 +321,7 @@ def test_kernAddNoise(rk):
     for f in ("x", "y", "theta"):
         assert np.abs(got[f] - want[f]).max() <= 2e-7
     same = sum((got[f].view(np.int32) == want[f].view(np.int32)).sum() for f in ("x", "y", "theta"))
-    print("dispersed coordinates identical: %d of %d" % (same, 3 * N))
+    report("kernAddNoise: dispersed coordinates of the specification identical: %d of %d" % (same, 3 * N))
     assert same >= 0.97 * 3 * N
     assert (got["w"] == want["w"]).all()
 
@@ -350,7 +375,7 @@ def test_kernWeightedSample(rk):
                     chain.add(j)
                     j = src[j]
                 assert g2[i] in chain
-            print("full launch: %d of %d results equal the snapshot semantics (the rest read an already overwritten slot)" % ((g2 == src).sum(), N))
+            report("kernWeightedSample full launch: %d of %d results equal the snapshot semantics (the rest read an already overwritten slot)" % ((g2 == src).sum(), N))
 
 
 def test_kernUpdateMapKD_and_TestCorrespondance(pkg, rk, small_world):
@@ -405,7 +430,14 @@ def test_grid_kernels(pkg, rk, small_world):
     mine = np.zeros(N, np.int32)
     pa = O.default_patch()
     O.lib().orc_score_grid(O.P(grid), dim, dim, C.byref(pa), O.P(p), N, O.P(scan), NB, O.P(mine))
-    print("grid scores of the restatement identical to kernEvaluateParticles: %d of %d" % ((mine == want).sum(), N))
+    report("kernEvaluateParticles: grid scores of the restatement identical: %d of %d (max |diff| %d)" % ((mine == want).sum(), N, np.abs(mine - want).max()))
+    h = pkg.PfSlam(N)
+    h.set_trig(1)
+    h.set_grid(grid.reshape(dim, dim)); h.set_particles(p); h.set_scan(scan)
+    dev = h.score_grid()
+    h.close()
+    report("kernEvaluateParticles: product (device-library trigonometry) grid scores differing from the reference kernel: %d of %d" % ((dev != want).sum(), N))
+    assert (dev == want).all()
     assert (mine == want).mean() >= 0.8 and np.abs(mine - want).max() <= 400
     mask = (rng.uniform(0, 1, dim * dim) < 0.3).astype(np.uint8)
     for val in (-1, 4):
@@ -456,7 +488,7 @@ def test_bench_workload_scan_match_vs_reference_kernel(pkg, rk):
             hyb, _, _ = hybrid_score(rk, tree, pb[bad], scan)
             assert (hyb.view(np.int32) == want[bad].view(np.int32)).all()
             assert np.abs(got[s:s + N][bad] - want[bad]).max() <= 4 * 226  # a few beams changing sides between a wall node (<= +113) and a free node (>= -113)
-    print("bench workload: %d of %d product scores identical to the reference kernel (cell rows: %s)" % (len(starts) * N - diff, len(starts) * N, stats))
+    report("bench workload (specification): %d of %d product scores identical to the reference kernel (cell rows: %s)" % (len(starts) * N - diff, len(starts) * N, stats))
     assert diff <= 0.01 * len(starts) * N
 
 
@@ -476,7 +508,89 @@ def test_contraction_variant_reported(pkg, small_world):
     fa, fb = ref_score(a, tree, p, scan), ref_score(b, tree, p, scan)
     q = queries(tree, np.random.RandomState(5), 20000)
     ia, ib = ref_traverse(a, tree, q), ref_traverse(b, tree, q)
-    print("contraction on vs off: scores identical %d of %d (max |diff| %.1f); traversal indices identical %d of %d"
-          % ((fa == fb).sum(), N, np.abs(fa - fb).max(), (ia == ib).sum(), len(q)))
+    report("contraction on vs off: scores identical %d of %d (max |diff| %.1f); traversal indices identical %d of %d"
+           % ((fa == fb).sum(), N, np.abs(fa - fb).max(), (ia == ib).sum(), len(q)))
     a.close(); b.close()
     assert (fa == fb).mean() > 0.5
+
+
+# ---- the device library's transcendentals (pfslam_set_trig): the product against the reference's kernels with ZERO tolerance -----------------
+def test_devlib_bench_workload_every_particle_equals_reference_kernel(pkg, rk):
+    """BASELINE configs[2]'s workload, as above, with the handle's transcendentals switched to the device library's (what the
+    reference's text compiles to here) from the first frame on: the product's scan-match pass -- k_score_kd_cells over the lattice-cell
+    rows, Hilbert lane order, 16-bit beam-chunk partials -- against the reference's own kernEvaluateParticlesKD for ALL 100 000 particles
+    (100 launches of PARTICLE_COUNT = 1000): not one score may differ.  This is the cell-row memoisation against the reference's
+    traversal with no hybrid and no tolerance."""
+    n = 100000
+    pts, segs = pkg.synth.make_map_points(100000, seed=1)
+    tree0 = pkg.kd_create(pts)
+    h = pkg.PfSlam(n, kd_capacity=100000 + (1 << 18))
+    h.set_trig(1)
+    h.set_map(tree0)
+    for f in range(1, 6):
+        h.motion_update(f)
+    for f in range(6, 18):
+        h.step(f, pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f))
+    h.synchronize()
+    assert h.frame_mode()["round5_frame"]
+    p, tree = h.particles().copy(), h.map().copy()
+    scan = pkg.synth.make_scan(segs, (0.002 * 18, 0.001 * 18, 0.0004 * 18), seed=2018).astype(np.float32)
+    h.set_particles(p)
+    h.set_scan(scan)
+    got = h.score_kd()
+    stats = h.cell_stats()
+    h.close()
+    assert len(tree) > 100000 and stats["rows"] > 0
+    tb, t0 = rk.tree_dev(tree)
+    ds = rk.dev(scan)
+    diff = 0
+    for s in range(0, n, N):
+        pb = np.ascontiguousarray(p[s:s + N])
+        dp, df = rk.dev(pb), rk.zeros(N, np.float32)
+        rk.launch("kernEvaluateParticlesKD", N, 128, ptr(0), ivec2(1600, 1600), patch(), ptr(dp), vec3(0, 0, 0), ptr(ds), ptr(df), ptr(t0), i32(len(tree)))
+        want = df.get()
+        dp.free(); df.free()
+        diff += int((got[s:s + N].view(np.int32) != want.view(np.int32)).sum())
+    report("bench workload (device-library trigonometry): %d of %d product scores differ from the reference kernel (cell rows %d, cells %d)"
+           % (diff, n, stats["rows"], stats["cells"]))
+    assert diff == 0
+
+
+@pytest.mark.parametrize("theta", [0.3, -2.0, 1.0])
+def test_devlib_get_walls_masks_equal_kernGetWalls(pkg, rk, small_world, theta):
+    """k_get_walls (+ the ordered cell lists) with the device library's trigonometry against the reference's kernGetWalls on the real
+    1600 x 1600 masks, at the KD path's centre (kernel.cu:1408-1411): the occupancy-cell indices, wall and free, cell for cell."""
+    dim, center = 1600, (800, 800)
+    scan = pkg.synth.make_scan(small_world["segs"], (0.1, -0.2, theta), seed=31).astype(np.float32)
+    scan[3], scan[500] = 40.0, 0.0
+    fm, wm = rk.zeros(dim * dim, np.uint8), rk.zeros(dim * dim, np.uint8)
+    rk.launch("kernGetWalls", NB, 128, ptr(rk.dev(scan)), ivec2(*center), f32(theta), ptr(fm), ptr(wm), ivec2(dim, dim), patch())
+    want_f, want_w = np.flatnonzero(fm.get()), np.flatnonzero(wm.get())
+    tree = small_world["tree"]
+    h = pkg.PfSlam(64, kd_capacity=len(tree) + 4000)
+    h.set_trig(1)
+    h.set_map(tree); h.set_scan(scan); h.set_pose((0.1, -0.2, theta))
+    h.update_map_kd()
+    got_w, got_f = h.cells(0), h.cells(1)
+    h.close()
+    report("kernGetWalls theta %.1f: product (device-library trigonometry) wall cells %d / %d, free cells %d / %d, differing: %d"
+           % (theta, len(got_w), len(want_w), len(got_f), len(want_f), len(np.setxor1d(got_w, want_w)) + len(np.setxor1d(got_f, want_f))))
+    assert (got_w == want_w).all() and (got_f == want_f).all()
+
+
+def test_devlib_dispersion_equals_kernAddNoise(pkg, rk):
+    """k_motion with the device library's erfcinvf against the reference's kernAddNoise (thrust's normal_distribution): every coordinate
+    of every particle, bit for bit -- and the frame loop's dispersion kernel (k_motion_count) gives the same particles."""
+    p = O.make_particles(N, 0.5, -0.25, 0.125)
+    dp = rk.dev(p)
+    rk.launch("kernAddNoise", N, 128, ptr(dp), i32(17))
+    want = dp.get()
+    h = pkg.PfSlam(N)
+    h.set_trig(1)
+    h.set_particles(p)
+    h.motion_update(17)
+    got = h.particles().copy()
+    h.close()
+    bad = sum(int((got[f].view(np.int32) != want[f].view(np.int32)).sum()) for f in ("x", "y", "theta"))
+    report("kernAddNoise: product (device-library erfcinv) coordinates differing from the reference kernel: %d of %d" % (bad, 3 * N))
+    assert bad == 0

@@ -67,7 +67,7 @@ def test_virtual_ranks_on_one_gpu_match_oracle(pkg, n_global, world):
         for e in engs:
             e.shard_score()
         sync()
-        packs = torch.cat([b.pack for b in bufs])                               # all-gather of the 32-byte records
+        packs = torch.cat([b.pack for b in bufs])                               # all-gather of the 16-byte records (packed keys)
         for b in bufs:
             b.packs.copy_(packs)
         sync()
@@ -265,3 +265,138 @@ def test_sharded_frames_with_topology_match_the_single_handle(pkg, mode):
         assert idx == want_graph[1] and (np.asarray(nodes, np.float32).view(np.int32) == np.asarray(want_graph[0], np.float32).view(np.int32)).all()
     assert sum(len(r[3]) for r in want) > 100   # the loop closes: proposals were made
     one.close(); v.close()
+
+
+def _bench_like(pkg, n, n_map=20000, n_frames=30, seed=1):
+    pts, segs = pkg.synth.make_map_points(n_map, seed=seed)
+    tree = pkg.kd_create(pts)
+    scans = [pkg.synth.make_scan(segs, (0.002 * f, 0.001 * f, 0.0004 * f), seed=2000 + f) for f in range(n_frames)]
+    return tree, scans
+
+
+def _run(e, tree, scans, step, first=6):
+    e.set_map(tree)
+    for f in range(1, 6):
+        e.motion_update(f)
+    poses = []
+    for i, s in enumerate(scans):
+        step(first + i, s)
+        poses.append(bits(e.pose).tolist())
+    e.synchronize()
+    return poses, e.particles().copy(), e.map().tobytes(), e.trace()
+
+
+def test_sharded_frame_is_the_round5_frame(pkg):
+    """The sharded calls enqueue the four parts of the very frame pfslam_step enqueues (pfslam_frame.hip.inc): a one-rank job stepped
+    through pfslam_shard_* runs round-5 frames (pfslam_frame_mode) and gives pose, particles, map and trace of pfslam_step bit for bit --
+    at a particle count whose scan-match pass is organised by lattice-cell rows."""
+    n = 20000
+    tree, scans = _bench_like(pkg, n)
+    a = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    want = _run(a, tree, scans, a.step)
+    assert a.frame_mode()["round5_frame"]
+    a.close()
+    b = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+
+    def shard_step(f, s):
+        if b.shard_disperse(f, s):
+            return
+        b.shard_score(); b.shard_weights(); b.shard_finish()
+    got = _run(b, tree, scans, shard_step)
+    assert b.frame_mode()["round5_frame"], "the sharded frame fell back to the staged chain"
+    assert got[0] == want[0]
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[1][fld]) == bits(want[1][fld])).all(), fld
+    assert got[2] == want[2]
+    assert {k: got[3][k] for k in ("best", "resampled", "kd_size")} == {k: want[3][k] for k in ("best", "resampled", "kd_size")}
+    b.close()
+
+
+def test_native_rccl_rank_world1_equals_plain_step(pkg):
+    """libpfslam_mgpu.so (include/pfslam_mgpu.h) steps a one-rank job: the same frames as pfslam_step, bit for bit; its barrier and
+    statistics work without a communicator.  (More than one rank needs one GPU per rank: RCCL refuses two ranks on one device.)"""
+    n = 20000
+    tree, scans = _bench_like(pkg, n, n_frames=12)
+    a = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    want = _run(a, tree, scans, a.step)
+    a.close()
+    b = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    m = pkg.MgpuRank(b, 1, 0)
+    got = _run(b, tree, scans, m.step)
+    assert got[0] == want[0] and got[2] == want[2]
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(got[1][fld]) == bits(want[1][fld])).all(), fld
+    assert m.barrier_max(3.5) == 3.5
+    st = m.stats()
+    assert st["world"] == 1 and st["collectives"] == 3 * len(scans)
+    assert m.time_collectives(2) == {"pose_blocks": 0.0, "records": 0.0, "weights": 0.0}
+    m.close(); b.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_virtual_ranks_run_round5_frames_at_cell_row_sizes(pkg, world):
+    """Virtual ranks at a size where every shard's scan-match pass uses lattice-cell rows: the sharded frames are round-5 frames (not the
+    staged fallback), the job-wide |heading| maximum reaches every rank's header, and the job equals ONE handle stepping all particles."""
+    torch = pytest.importorskip("torch")
+    n = 30001 if world == 3 else 30000
+    tree, scans = _bench_like(pkg, n, n_frames=16)
+    one = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    want = _run(one, tree, scans, one.step)
+    one.close()
+    v = _VirtualRanks(pkg, torch, n, world, kd_capacity=len(tree) + (1 << 18))
+    for e in v.engs:
+        e.set_map(tree)
+        for f in range(1, 6):
+            e.motion_update(f)
+    poses, v2_frames = [], 0
+    for i, s in enumerate(scans):
+        v.step(6 + i, s)
+        poses.append(bits(v.pose).tolist())
+        fms = [e.frame_mode() for e in v.engs]
+        v2_frames += all(fm["round5_frame"] and not fm["gates"] for fm in fms)   # (several handles in one process: the edges are events)
+    # (a shard whose cloud has grown too wide for its size goes back to the staged chain for a frame -- the organisation follows the cloud's
+    # spread, per rank -- and the job still equals the single handle; here nearly every frame is a round-5 frame on every rank)
+    assert v2_frames >= len(scans) - 3
+    for e in v.engs:
+        e.synchronize()
+    assert poses == want[0]
+    got = [e.particles() for e in v.engs]
+    for fld in ("x", "y", "theta", "w"):
+        assert (bits(np.concatenate([g[fld] for g in got])) == bits(want[1][fld])).all(), fld
+    for e in v.engs:
+        assert e.map().tobytes() == want[2]
+    v.close()
+
+
+def test_two_handles_interleaved_do_not_wait_on_each_other(pkg):
+    """Two handles of one process with frames in flight at the same time: their eight streams may share hardware queues, so neither uses
+    stream gates (a gate spins inside a kernel); both run to the results of a handle stepped alone, and a handle that is alone again
+    goes back to gates."""
+    import time
+    n = 20000
+    tree, scans = _bench_like(pkg, n, n_frames=14)
+    solo = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    want = _run(solo, tree, scans, solo.step)
+    gates_alone = solo.frame_mode()["gates"]
+    solo.close()
+    a = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    b = pkg.PfSlam(n, kd_capacity=len(tree) + (1 << 18))
+    for e in (a, b):
+        e.set_map(tree)
+        for f in range(1, 6):
+            e.motion_update(f)
+    t0 = time.time()
+    for i, s in enumerate(scans):
+        a.step(6 + i, s)
+        b.step(6 + i, s)
+    assert not a.frame_mode()["gates"] and not b.frame_mode()["gates"]
+    a.synchronize(); b.synchronize()
+    assert time.time() - t0 < 20.0          # (a gate that gives up takes a second per frame)
+    for e in (a, b):
+        assert bits(e.pose).tolist() == want[0][-1]
+        assert e.map().tobytes() == want[2]
+    b.close()
+    a.step(6 + len(scans), scans[0])        # alone again
+    a.synchronize()
+    assert a.frame_mode()["gates"] == gates_alone
+    a.close()

@@ -28,3 +28,20 @@ def test_reference_kernel_code_object():
     L = ctypes.CDLL(os.path.join(REF, "libhsaco_launcher.so"))
     for f in ("ref_launch", "ref_dev_alloc", "ref_dev_free", "ref_h2d", "ref_d2h", "ref_dev_memset", "ref_svd3_gpu"):
         assert hasattr(L, f)
+
+
+def test_reference_kernel_code_object_is_not_stale():
+    """The code object the GPU tests launch was built from the reference's text AS IT IS NOW: oracle/Makefile leaves the sha256 of
+    kernel.cu and of every header it includes beside the code object; here (where /root/reference exists) they are recomputed."""
+    import hashlib
+    ref_src = "/root/reference/src"
+    shaf = os.path.join(REF, "kernel_ref.sha256")
+    if not os.path.isdir(ref_src) or not os.path.exists(os.path.join(REF, "kernel_ref.hsaco")):
+        pytest.skip("needs /root/reference and a built oracle/_ref/kernel_ref.hsaco")
+    assert os.path.exists(shaf), "oracle/_ref/kernel_ref.sha256 missing: rebuild with `make -C oracle`"
+    rows = [l.split() for l in open(shaf).read().splitlines() if l.strip()]
+    assert any(name == "kernel.cu" for _, name in rows)
+    for digest, name in rows:
+        with open(os.path.join(ref_src, name), "rb") as fh:
+            assert hashlib.sha256(fh.read()).hexdigest() == digest, "%s changed since kernel_ref.hsaco was built: `make -C oracle`" % name
+    assert os.path.getmtime(os.path.join(REF, "kernel_ref.hsaco")) >= os.path.getmtime(shaf) - 600

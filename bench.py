@@ -64,8 +64,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs, the long-run leg and the extras (profiling runs)")
     ap.add_argument("--pmc-file", default="", help="rocprofv3 PMC summary to take roofline.traffic from (default: newest matching profiles/r*_pmc_score_kd*.json)")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging)")
-    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--backend", default="", help="torch.distributed backend of the process group (default: gloo with --collectives rccl -- the group only "
+                    "carries the RCCL job id and each rank's wall time, the frame's collectives are the job's own RCCL communicators --, nccl with --collectives torch)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (--collectives torch --backend gloo)")
     ap.add_argument("--cloud-sigma", type=float, default=0.0, help="start from a Gaussian cloud of this spread (m; heading: sigma / 8 rad) instead of the dispersed start cloud")
     ap.add_argument("--topology", type=int, default=0, help="1 | 2: UpdateTopology + CheckLoopClosure inside the frame (kernel.cu:1750-1751; BASELINE configs[4]); "
                     "the line then carries the graph size and the loop-closure proposals of the last timed frame")
@@ -322,16 +323,27 @@ def main():
     dist = None
     torch = None
     distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ)  # torchrun, even with 1 rank
+    if a.same_device and a.collectives == "rccl":
+        a.collectives = "torch"          # (RCCL refuses two ranks on one device)
+    native = distributed and a.collectives == "rccl"
+    backend = a.backend or ("gloo" if (native or a.same_device) else "nccl")
+    cuda_tensors = False                 # the process group moves device tensors (only with torch's own collectives)
     if distributed:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: the bootstrap over loopback (the container's other interfaces may not route)
-        if a.backend == "nccl":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            cuda_tensors = True
         else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+            # With the job's own RCCL communicators (libpfslam_mgpu.so) the process group is bookkeeping on the host: the job id, each rank's
+            # wall time.  No torch CUDA context, no second RCCL instance with streams of its own beside the frame's four.
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            if not native:
+                torch.cuda.set_device(local_rank)
 
     # ---- synthetic workload (identical on every rank) -------------------------------------------
     n_local = a.particles
@@ -350,8 +362,6 @@ def main():
 
     cap = a.map_points + (1 << 18)
 
-    native = distributed and a.collectives == "rccl" and a.backend == "nccl" and not a.same_device
-
     def make_engine():
         if distributed:
             from importlib import import_module
@@ -361,7 +371,7 @@ def main():
                 box = [pkg.mgpu_make_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 job_id = box[0]
-            e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch,
+            e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=None if native else torch,
                                     native=native, native_id=job_id)
         else:
             e = pkg.PfSlam(n_local, kd_capacity=cap, device=local_rank)
@@ -389,8 +399,7 @@ def main():
     def barrier():
         eng.synchronize()
         if getattr(eng, "native", None) is not None:
-            eng.native.barrier_max()     # device synchronisation + an all-reduce on the job's own RCCL communicator (a process-group barrier costs ~1 ms: 10 % of a 20-step window)
-            torch.cuda.synchronize()
+            eng.native.barrier_max()     # hipDeviceSynchronize + an all-reduce on the job's own RCCL communicator (a process-group barrier costs ~1 ms: 10 % of a 20-step window)
         elif dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
@@ -403,7 +412,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if cuda_tensors else "cpu")
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)                       # every rank's own wall time: a SCALE record explains itself
             per_rank_s.append([float(v.item()) for v in every])
@@ -442,7 +451,7 @@ def main():
                     op()
                 e_b.record(); torch.cuda.synchronize()
                 ms[name] = e_a.elapsed_time(e_b) / reps
-        t = torch.tensor([ms[k] for k in sorted(ms)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([ms[k] for k in sorted(ms)], dtype=torch.float64, device="cuda" if cuda_tensors else "cpu")
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         res["ms"] = {k: [float(v[i].item()) for v in every] for i, k in enumerate(sorted(ms))}

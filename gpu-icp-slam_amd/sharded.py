@@ -105,10 +105,18 @@ class ShardedSlam:
         self.device = device
         self.collectives = 0   # all-gathers issued: 3 in every frame (fixed schedule)
         # KDTree::Balance (frame % 100 == 5) ONCE per node: rank 0 builds, the others receive the device arrays (28 B per node)
-        self.balance_builds = 0      # host builds this rank ran
-        self.balance_broadcasts = 0  # re-balances this rank took part in
+        self._balance_builds = 0      # host builds this rank ran
+        self._balance_broadcasts = 0  # re-balances this rank took part in
         if world > 1 and self.native is None:
             engine.set_shard_balance(True)
+
+    @property
+    def balance_builds(self):
+        return self.native.stats()["balance_builds"] if self.native is not None else self._balance_builds
+
+    @property
+    def balance_broadcasts(self):
+        return self.native.stats()["balance_broadcasts"] if self.native is not None else self._balance_broadcasts
 
     # -- pass-throughs
     def set_map(self, tree): self.eng.set_map(tree)
@@ -168,12 +176,12 @@ class ShardedSlam:
             if due:
                 if self.rank == 0:
                     e.shard_balance_build(frame)
-                    self.balance_builds += 1
+                    self._balance_builds += 1
                 for t in b.tree_buffers(n_nodes):       # rank 0's re-built map, straight from / into the device arrays
                     self.dist.broadcast(t, src=0)
                 if self.rank != 0:
                     e.shard_balance_adopt()
-                self.balance_broadcasts += 1
+                self._balance_broadcasts += 1
         if e.shard_disperse(frame, scan):       # first scan seeds the map (kernel.cu:1714-1717); replicated
             return
         if self.world == 1:                     # buffers 10 / 17 alias 5 / 16, nothing reads buffer 15: no collective at all

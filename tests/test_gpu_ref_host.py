@@ -90,13 +90,17 @@ def test_reference_frame_loop_against_the_product(pkg, tmp_path):
     n_frames = 40
     segs, seq = pkg.synth.corridor_sequence(n_frames + 1, seed=5)
     scans = np.stack([s for _, s in seq]).astype(np.float32)   # the reference reads scans[frame] (kernel.cu:1716); frames start at 1 (H9)
+    # H2: the ICP targets of beams beyond the +-20 m window are never written (kernel.cu:984-990) and the buffer is a fresh cudaMalloc
+    # (1006) -- zeros on CUDA in practice, whatever an earlier allocation left there on this runtime (a NaN pose two frames in).  Every
+    # beam in range, then: the comparison is about defined behaviour.
+    scans = np.minimum(scans, np.float32(19.0))
     assert pkg.device_count() > 0   # (the product's library talks to the runtime first: loaded the other way round, its device query fails)
     h = pkg.PfSlam(1000, kd_capacity=1 << 18, free_upload_bug=1, strict_host_mirror=1)
     ref = RefHost(tmp_path, scans)
     assert ref.n == 1000            # PARTICLE_COUNT, kernel.cu:30
     h.set_trig(1)
     stats = {"frames": 0, "pose_bits": 0, "pose_max_err": 0.0, "tree_struct": 0, "tree_weights": 0, "particles_no_resample": 0, "no_resample_frames": 0,
-             "resample_frames": 0, "resample_decision": 0, "stage_tree": 0, "stage_frames": 0, "weights_lost": 0}
+             "resample_frames": 0, "resample_decision": 0, "stage_tree": 0, "stage_frames": 0, "weights_lost": 0, "h11_second_half_stale": 0, "weights_lost_product_minus_reference": {}}
     for f in range(1, n_frames + 1):
         p0, pose0, t0 = ref.get()               # the state the reference's frame f starts from ...
         if len(t0):
@@ -117,34 +121,64 @@ def test_reference_frame_loop_against_the_product(pkg, tmp_path):
         same_struct = all((ht[k] == t1[k]).all() for k in ("axis", "left", "right", "parent")) and all((bits(ht[k]) == bits(t1[k])).all() for k in ("x", "y", "z"))
         stats["tree_struct"] += int(same_struct)
         wdiff = int((bits(ht["w"]) != bits(t1["w"])).sum())
+        if wdiff and os.environ.get("PFSLAM_REFHOST_DEBUG"):
+            j = np.flatnonzero(bits(ht["w"]) != bits(t1["w"]))
+            print("frame", f, "tree weights differing", wdiff, "first:", [(int(k), float(ht["w"][k]), float(t1["w"][k]), float(t0["w"][k]) if k < len(t0) else None) for k in j[:6]],
+                  "histogram of (product - reference):", np.unique((ht["w"][j] - t1["w"][j]).round(), return_counts=True), flush=True)
         stats["tree_weights"] += int(wdiff == 0)
         stats["weights_lost"] += wdiff
-        # did the frame resample?  (the reference's particles all carry w == 1 behind a resample: kernel.cu:441-442)
-        ref_resampled = bool((p1["w"] == 1.0).all()) and f > 1
-        stats["resample_decision"] += int(bool(tr["resampled"]) == ref_resampled or f == 1)
-        if f > 1 and not ref_resampled:
+        if wdiff:   # H4: kernUpdateMapKD's read-modify-write is not atomic (kernel.cu:1361); the product applies every hit
+            j = np.flatnonzero(bits(ht["w"]) != bits(t1["w"]))
+            for v, c in zip(*np.unique((ht["w"][j] - t1["w"][j]).round().astype(int), return_counts=True)):
+                stats["weights_lost_product_minus_reference"][int(v)] = stats["weights_lost_product_minus_reference"].get(int(v), 0) + int(c)
+        # did the frame resample?  The product says so (its trace); the reference shows it: behind a resample every weight is 1 (kernel.cu:441-442),
+        # without one every particle is its dispersed self.
+        half = (ref.n + 1) // 2
+        same_xyt = all((bits(hp[k]) == bits(p1[k])).all() for k in ("x", "y", "theta"))
+        if f > 1 and not tr["resampled"]:
             stats["no_resample_frames"] += 1
-            ok = all((bits(hp[k]) == bits(p1[k])).all() for k in ("x", "y", "theta", "w"))
+            # positions and headings of every particle (the dispersion, kernel.cu:375-397); the weights of the first half of the array -- all
+            # the reference's host copy ever sees of a measurement update (H11: kernel.cu:1341 reads back PARTICLE_COUNT / 2 particles'
+            # worth of bytes); the second half of ITS array keeps what the frame started from
+            ok = same_xyt and (bits(hp["w"][:half]) == bits(p1["w"][:half])).all()
             stats["particles_no_resample"] += int(ok)
+            stats["h11_second_half_stale"] += int((bits(p1["w"][half:]) == bits(p0["w"][half:])).all())
+            same_decision = ok
         elif f > 1:
             stats["resample_frames"] += 1
+            same_decision = bool((p1["w"] == 1.0).all()) and bool((hp["w"] == 1.0).all())
+            # (which particle lands where is the reference's in-place race, H3: tests/test_gpu_ref_kernels.py has the drawn indices)
+        else:
+            same_decision = same_xyt
+        stats["resample_decision"] += int(same_decision)
+        if not same_decision:   # Neff = (sum w)^2 / sum w^2 with thrust::reduce's sums on the reference's side: only a frame ON the threshold may differ
+            report("frame %d: resample decision / particles differ (product resampled: %s), product's Neff %.4f against the threshold %.1f"
+                   % (f, bool(tr["resampled"]), tr["neff"], 0.7 * ref.n))
+            assert abs(tr["neff"] - 0.7 * ref.n) < 0.05
         # the map update on its own, AT THE REFERENCE'S POSE (takes the ICP sums' order out of the comparison): PFUpdateMapKD's lists, snapping,
         # H6 upload, weight passes, new-wall test and insert order must give the reference's tree, byte for byte in structure
         if len(t0):
             g = pkg.PfSlam(64, kd_capacity=1 << 18, free_upload_bug=1)
             g.set_trig(1)
             g.set_map(t0); g.set_scan(scans[f]); g.set_pose(pose1)
+            g.maybe_balance(f)                   # KDTree::Balance in front of frame % 100 == 5 (kernel.cu:1707-1711)
             g.update_map_kd()
             gt = g.map().copy()
             g.close()
             stats["stage_frames"] += 1
             ok = len(gt) == len(t1) and all((gt[k] == t1[k]).all() for k in ("axis", "left", "right", "parent")) and all((bits(gt[k]) == bits(t1[k])).all() for k in ("x", "y", "z"))
             stats["stage_tree"] += int(ok)
-            assert ok, "frame %d: PFUpdateMapKD at the reference's pose gives another tree" % f
+            if not ok:
+                report("frame %d: PFUpdateMapKD at the reference's pose gives another tree (%d nodes vs %d)" % (f, len(gt), len(t1)))
     h.close()
     ref.close()
     report("reference frame loop (kernel.cu whole, %d frames x 1000 particles, product stepped from the reference's state): %s" % (n_frames, stats))
     assert stats["stage_tree"] == stats["stage_frames"] > 0
     assert stats["tree_struct"] >= stats["frames"] - 2          # (a pose differing in its last place may move a cell's snapped coordinate)
-    assert stats["resample_decision"] == stats["frames"]
-    assert stats["particles_no_resample"] == stats["no_resample_frames"]
+    assert stats["resample_decision"] >= stats["frames"] - 1
+    assert stats["particles_no_resample"] == stats["no_resample_frames"] == stats["h11_second_half_stale"] > 0
+    # H4 as the reference really behaves: several cells of a pass that hit ONE node lose all but one of their updates when their threads
+    # run together -- the product (and the restatement) apply every hit: the differences are whole multiples of the two weights, on a
+    # few dozen of some thousand nodes per frame
+    assert all(v % 1 == 0 and (v % 4 == 0 or -8 <= v < 0) for v in stats["weights_lost_product_minus_reference"])
+    assert stats["weights_lost"] < 0.05 * stats["frames"] * 1000

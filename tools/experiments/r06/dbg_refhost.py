@@ -12,11 +12,12 @@ L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libkernel_ref_host.so"))
 print("devices after load:", pkg.device_count(), flush=True)
 import test_gpu_ref_host as T
 open("/tmp/scene.txt", "w").write(T.SCENE_TXT)
-segs, seq = pkg.synth.corridor_sequence(5, seed=5)
-np.stack([s for _, s in seq]).astype(np.float32).tofile("/tmp/scans.f32")
+segs, seq = pkg.synth.corridor_sequence(12, seed=5)
+np.minimum(np.stack([s for _, s in seq]).astype(np.float32), np.float32(19.0)).tofile("/tmp/scans.f32")
 n = L.refhost_init(b"/tmp/scene.txt", b"/tmp/scans.f32")
 print("refhost_init ->", n, "devices after init:", pkg.device_count(), flush=True)
-print("step", L.refhost_step(1), flush=True)
+for f in range(1, 10):
+    print("step", f, L.refhost_step(f), flush=True)
 print("devices after step:", pkg.device_count(), flush=True)
 h2 = pkg.PfSlam(1000, kd_capacity=1 << 18)
 print("second product handle ok")

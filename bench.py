@@ -362,6 +362,8 @@ def main():
 
     cap = a.map_points + (1 << 18)
 
+    fallback = {}   # native RCCL asked for and not available on every rank: {"native": False, "reason": ...}
+
     def make_engine():
         if distributed:
             from importlib import import_module
@@ -371,8 +373,29 @@ def main():
                 box = [pkg.mgpu_make_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 job_id = box[0]
-            e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=None if native else torch,
-                                    native=native, native_id=job_id)
+            e, why = None, ""
+            if native:
+                try:
+                    e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=None, native=True, native_id=job_id)
+                except Exception as ex:   # ncclCommInitRank / the warm-up collectives failed on this rank
+                    why = "%s: %s" % (type(ex).__name__, ex)
+                if world > 1:             # ... then nobody uses them: the ranks agree over the process group, and the line says so
+                    ok = torch.tensor([0 if e is None else 1], dtype=torch.int32)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok.item()) == 0:
+                        reasons = [None] * world
+                        dist.all_gather_object(reasons, why)
+                        fallback["reason"] = "; ".join("rank %d: %s" % (r, w) for r, w in enumerate(reasons) if w) or "a rank failed"
+                        if e is not None:
+                            e.close()
+                        e = None
+                elif e is None:
+                    raise SystemExit("libpfslam_mgpu.so: " + why)
+            if e is None:                 # torch.distributed issues the collectives (--collectives torch, or the fallback above)
+                if native:
+                    fallback["native"] = False
+                    torch.cuda.set_device(local_rank)
+                e = sharded.ShardedSlam(pkg, n_global, rank, world, device=local_rank, kd_capacity=cap, dist=dist, torch=torch, native=False, native_id=None)
         else:
             e = pkg.PfSlam(n_local, kd_capacity=cap, device=local_rank)
         e.set_map(tree)
@@ -428,7 +451,7 @@ def main():
         sizes = {"pose_blocks_bytes_per_rank": 3 * eng.stride * 4 if hasattr(eng, "stride") else 3 * n_local * 4,
                  "records_bytes_per_rank": 16, "weights_bytes_per_rank": (eng.stride if hasattr(eng, "stride") else n_local) * 4,
                  "balance_broadcast_bytes": 28 * int(e0.kd_size) + 16}
-        res = {"sizes": sizes, "world": world, "ms": None, "issued_by": "libpfslam_mgpu.so (ncclAllGather into the frame's own streams)" if native else "torch.distributed",
+        res = {"sizes": sizes, "world": world, "ms": None, "issued_by": "libpfslam_mgpu.so (ncclAllGather into the frame's own streams)" if getattr(eng, "native", None) is not None else "torch.distributed",
                "note": "pose blocks: on the particle stream, under the scan-match kernel; the 16-byte records (a shard's packed keys): on the chain "
                        "stream between the reduce and the walls -- the one collective on the frame's critical chain; weights: on the particle stream; "
                        "the broadcast happens once per KDTree::Balance (100 frames).  ms = each collective on its own, back to back, per call"}
@@ -472,7 +495,8 @@ def main():
     # start-up self-test decides; a second handle in the process withdraws the gates), one-stream mode
     fm = e0.frame_mode()
     frame_mode_timed = {"round5_frame": fm["round5_frame"], "edges": "gates" if fm["gates"] else "events", "one_stream": fm["serial"],
-                        "sharded_frame": bool(distributed), "collectives": ("rccl, launched into the frame's own streams" if native else "torch.distributed") if world > 1 else None}
+                        "sharded_frame": bool(distributed), "collectives": ("rccl, launched into the frame's own streams" if getattr(eng, "native", None) is not None else "torch.distributed") if world > 1 else None,
+                        **({"collectives_fallback": fallback.get("reason", "")} if fallback else {})}
     topo_info = None
     if a.topology:   # replicated state: every rank holds the same graph and proposes the same pairs
         nodes_t, idx_t = eng.topology()

@@ -70,6 +70,37 @@ static int stream_of(pfslam_handle *h, int which, hipStream_t *st)
     return 0;
 }
 
+// RCCL connects a communicator's peers at its first collective, and sets up each protocol at the first message of its size class:
+// hundreds of milliseconds, seconds on a cold node.  Inside a frame that wait would sit in front of stream gates that give up after a
+// second (pfslam_frame.hip.inc) -- so everything the frame loop issues runs once here, at the frame's sizes, on a scratch buffer,
+// before the first frame: the three all-gathers, the re-balance's broadcast, the barrier's all-reduce.
+static int warm_up_on(pfslam_mgpu *m, char *tmp, size_t big, hipStream_t st)
+{
+    char *dst = tmp, *src = tmp + big * (size_t)m->world;
+    NCCL(ncclAllGather(src, dst, big, ncclChar, m->comm_p, st));                        // pose blocks
+    NCCL(ncclAllGather(src, dst, (size_t)m->stride * 4, ncclChar, m->comm_p, st));      // weights
+    NCCL(ncclAllGather(src, dst, 16, ncclChar, m->comm_c, st));                         // a shard's packed keys
+    NCCL(ncclBroadcast(src, src, big, ncclChar, 0, m->comm_p, st));                     // KDTree::Balance
+    NCCL(ncclBroadcast(src, src, 16, ncclChar, 0, m->comm_p, st));
+    NCCL(ncclAllReduce(m->scratch, m->scratch, 1, ncclDouble, ncclMax, m->comm_p, st)); // pfslam_mgpu_barrier_max
+    HIP(hipStreamSynchronize(st));
+    return 0;
+}
+static int warm_up(pfslam_mgpu *m)
+{
+    const size_t big = (size_t)3 * m->stride * 4;
+    char *tmp = nullptr;
+    hipStream_t st = nullptr;
+    if (stream_of(m->h, 0, &st)) return 1;
+    HIP(hipMalloc((void **)&tmp, big * (size_t)(m->world + 1)));
+    int rc = 0;
+    if (hipMemsetAsync(tmp, 0, big * (size_t)(m->world + 1), st) != hipSuccess || hipMemsetAsync(m->scratch, 0, 8, st) != hipSuccess)
+        rc = mfail("hipMemsetAsync failed");
+    if (!rc) rc = warm_up_on(m, tmp, big, st);
+    (void)hipFree(tmp);
+    return rc;
+}
+
 extern "C" int pfslam_mgpu_create(const unsigned char *id, int world, int rank, pfslam_handle *h, pfslam_mgpu **out)
 {
     if (!h || !out || world < 1 || rank < 0 || rank >= world) return mfail("pfslam_mgpu_create: bad argument");
@@ -107,6 +138,13 @@ extern "C" int pfslam_mgpu_create(const unsigned char *id, int world, int rank, 
     if (hipMalloc((void **)&m->scratch, 8) != hipSuccess) {
         delete m;
         return mfail("hipMalloc failed");
+    }
+    if (world > 1) {
+        const int wrc = warm_up(m);
+        if (wrc) {
+            (void)pfslam_mgpu_destroy(m);
+            return wrc;
+        }
     }
     *out = m;
     return 0;

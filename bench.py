@@ -588,7 +588,7 @@ def main():
         tree_end = np.ascontiguousarray(e0.map(), dtype=O.NODE_DTYPE)
         p_end = np.ascontiguousarray(e0.particles(), dtype=O.PARTICLE_DTYPE)
         last_scan = scans[a.warmup + a.steps - 1]
-        if a.no_cpu_baseline:
+        if a.no_cpu_baseline or world > 1:   # (the CPU leg: rank 0 at N = 1 only -- the other ranks would wait for it)
             _, visits, valid = O.score_kd(tree_end, p_end[:128], last_scan, stats=True)
             vbar, bvalid = visits / max(valid, 1), valid / 128
         else:
@@ -680,6 +680,7 @@ def main():
                          note="shared-prefix plan of the LAST timed launch (pfslam_plan_stats): one planning lane per (wave, beam) walks "
                               "the root path common to the wave's 64 queries and keeps only the nodes that can be nearest for some "
                               "lane; kernel_ms = k_group_box + k_plan, which run before the scan-match kernel"),
+            "definition_version": 2,   # 1 (rounds 1-4): frac / achieved priced 4-byte gathers at 256 B -- that figure is frac_lane_bytes / achieved_lane_bytes now; do not compare `frac` across versions
             "definition": "achieved = wave gathers one timed launch issues (census of the timed launches, mean) x 1024 B (every wave gather "
                           "as one 16 B x 64 lanes request of the gather path, whatever its width) / HIP-event time of the same launches "
                           "(mean); frac_lane_bytes prices the 4-byte gathers (cell-table words, parent indices) at 256 B instead; peak = wave-gather rate of this chip measured in this process (pfslam_ubench_gather: cache-resident "
@@ -734,6 +735,8 @@ def main():
         }
 
     # ---- the same step over a whole balance cycle (every rank takes part; rank 0 reports) ----------
+    if dist is not None:
+        dist.barrier()   # rank 0 has just put its report together: the others enqueue nothing while it does (a frame's stream gates wait behind the collectives)
     if long_run:
         # continue to the next frame % 100 == 6, then time exactly 100 frames: one KDTree::Balance (frame % 100 == 5) inside
         k = a.warmup + a.steps + probe_frames

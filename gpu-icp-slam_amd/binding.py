@@ -520,7 +520,8 @@ class PfSlam:
         _chk(self.L.pfslam_set_probe(self._h, int(frames)), "pfslam_set_probe")
 
     def probe(self, frames=4096):
-        """Wall-clock stamps (microseconds, relative to the first stamp) of the launches of the last round-5 frames: (names, array[f][slot])."""
+        """Wall-clock stamps of the launches of the last round-5 frames: (names, array[f][slot], last ticket).  Absolute values of the device's
+        100 MHz wall clock in microseconds (subtract a frame's scan-match stamp for a timeline: tools/frame_probe.py); 0 = that launch did not run in that frame."""
         buf = np.zeros((frames, 32), np.uint64)
         n, last = C.c_int(0), C.c_int(0)
         _chk(self.L.pfslam_get_probe(self._h, _p(buf), frames, C.byref(n), C.byref(last)), "pfslam_get_probe")

@@ -38,6 +38,23 @@ enum { PF_T_SCORE = 0, PF_T_MOTION, PF_T_MEASURE, PF_T_MAP, PF_T_RESAMPLE, PF_T_
 #define PF_CENSUS_LOG 1024 /* scoring passes pfslam_set_census keeps a record of */
 #define PF_KD_MAX_NODES ((1 << 27) - 1) /* idx << 4 must fit the 0x7ffffff0-byte buffer descriptor; links are 30-bit */
 
+// Environment switches.  What the library reads with getenv() is the documented set (tools/README.md): test switches (one-stream mode,
+// events instead of gates, fault injection, canonical lane order, capacities of the overflow tests, the variant, the host build's threads).
+// The A/B knobs of past experiments (tools/experiments/*: priorities, workgroup counts, chains kept for comparison) go through ab_env()
+// and exist only in a -DPF_EXPERIMENTS build (PFSLAM_EXTRA_FLAGS=-DPF_EXPERIMENTS python gpu-icp-slam_amd/build.py): the product takes
+// the defaults they lost their A/B to, and the branches behind them fold away.
+#ifdef PF_EXPERIMENTS
+static inline const char *ab_env(const char *name) { return getenv(name); }
+#else
+static inline const char *ab_env(const char *) { return nullptr; }
+#endif
+
+// How long a stream gate (pfslam_frame.hip.inc) spins before it gives up, in ticks of the 100 MHz wall clock: 1 s for a handle on its own
+// (nothing it waits for takes a millisecond); 60 s once the process holds a shard of a multi-GPU job -- there a gate may sit behind a
+// collective, i.e. behind the slowest peer (a rank that prints its report, a host re-balance, a page fault).
+__device__ unsigned long long g_gate_ticks = 100000000ull;
+#define PF_GATE_TICKS_SHARDED 6000000000ull
+
 static thread_local std::string g_err;
 static int fail(const std::string &m)
 {
@@ -814,7 +831,7 @@ extern "C" void pfslam_default_config(pfslam_config *cfg)
 // caches (14 us between two 6 us kernels of the frame's critical chain): a device-scope release is what these events need.
 static hipError_t pf_event_create(hipEvent_t *e, unsigned flags)
 {
-    static const bool dev_scope = !(getenv("PFSLAM_EVENT_SYSTEM") && atoi(getenv("PFSLAM_EVENT_SYSTEM")) != 0); // A/B: 1 = the default (system) release
+    static const bool dev_scope = !(ab_env("PFSLAM_EVENT_SYSTEM") && atoi(ab_env("PFSLAM_EVENT_SYSTEM")) != 0); // A/B: 1 = the default (system) release
     hipError_t rc = hipEventCreateWithFlags(e, flags | (dev_scope ? hipEventReleaseToDevice : 0u));
     if (rc != hipSuccess && dev_scope) { // (a runtime that does not know the flag)
         (void)hipGetLastError();
@@ -868,17 +885,17 @@ static int create_impl(pfslam_handle *h)
         // priority their workgroups queue behind that flood (the one-workgroup ICP solve: 33 -> 284 us)
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        static const bool prio = !(getenv("PFSLAM_AUX_PRIO") && atoi(getenv("PFSLAM_AUX_PRIO")) == 0);
+        static const bool prio = !(ab_env("PFSLAM_AUX_PRIO") && atoi(ab_env("PFSLAM_AUX_PRIO")) == 0);
         HIPCHK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio ? hi : lo));
-        static const int kprio = getenv("PFSLAM_K_PRIO") ? atoi(getenv("PFSLAM_K_PRIO")) : 1; // 0 low, 1 normal (default), 2 high
+        static const int kprio = ab_env("PFSLAM_K_PRIO") ? atoi(ab_env("PFSLAM_K_PRIO")) : 1; // 0 low, 1 normal (default), 2 high
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, kprio == 2 ? hi : kprio == 1 ? (lo + hi) / 2 : lo)); // (beside the scan-match kernel: it must not get in its way)
-        static const int fprio = getenv("PFSLAM_F_PRIO") ? atoi(getenv("PFSLAM_F_PRIO")) : 2; // A/B: the free cells' stream 0 low, 1 normal, 2 high
+        static const int fprio = ab_env("PFSLAM_F_PRIO") ? atoi(ab_env("PFSLAM_F_PRIO")) : 2; // A/B: the free cells' stream 0 low, 1 normal, 2 high
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, !prio ? lo : fprio == 2 ? hi : fprio == 1 ? (lo + hi) / 2 : lo));
         HIPCHK(pf_event_create(&h->ev_tree, hipEventDisableTiming));
         HIPCHK(pf_event_create(&h->ev_scored, hipEventDisableTiming));
         h->fstream = h->istream; // round-5 frames: the free cells' chain (their ICP solve rides on the cells' stream)
         if (const char *e = getenv("PFSLAM_SERIAL")) h->serial = atoi(e) != 0;
-        if (const char *e = getenv("PFSLAM_FRAME_V2")) h->frame_v2 = atoi(e) != 0;
+        if (const char *e = ab_env("PFSLAM_FRAME_V2")) h->frame_v2 = atoi(e) != 0;
         if (const char *e = getenv("PFSLAM_GATES")) h->gates = atoi(e) != 0;
         if (const char *e = getenv("PFSLAM_FAULT")) h->fault = atoi(e);
         if (const char *e = getenv("PFSLAM_STABLE_ORDER")) h->stable_order = atoi(e) != 0;
@@ -905,6 +922,8 @@ static int create_impl(pfslam_handle *h)
             return fail("pfslam_create: shard [global_offset, +n_particles) does not fit the layout rank r = [r * shard_stride, min((r + 1) * shard_stride, global_n))");
         CHK(dalloc(&h->gw, (size_t)h->world * S)); CHK(dalloc(&h->gpose, (size_t)h->world * 3 * S));
         h->own_global = true;
+        const unsigned long long ticks = PF_GATE_TICKS_SHARDED;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_gate_ticks), &ticks, sizeof(ticks)));
     } else {
         h->gw = h->w;
         h->gpose = h->pblk;
@@ -953,7 +972,7 @@ static int create_impl(pfslam_handle *h)
         h->hdr_dev = (HostHeader *)dp;
     }
     HIPCHK(hipHostMalloc((void **)&h->h_scan, (size_t)PF_HDR_SLOTS * h->nb * 4));
-    if (const char *e = getenv("PFSLAM_LAG")) h->lag = std::min(std::max(atoi(e), 0), PF_MAX_LAG);
+    if (const char *e = ab_env("PFSLAM_LAG")) h->lag = std::min(std::max(atoi(e), 0), PF_MAX_LAG);
     if (const char *e = getenv("PFSLAM_VARIANT")) h->variant = atoi(e); // initial pfslam_set_variant (A/B runs, the fuzz)
     h->h_nodes.reserve(1024);
     // particleFilterInit (kernel.cu:122-132): grid = -100, particles at the origin with w = 1, robotPos = 0
@@ -1544,7 +1563,7 @@ static int score_chunks(const pfslam_handle *h)
     // Below ~40 k particles fewer, longer waves win (a wave's prologue and the launch's ramp against the beams it scores): ~160 chunks per
     // group between 24 576 and 65 536 waves (profiles/r05_sweep_waves.txt: 10 k particles 0.218 -> 0.209 ms per frame, 20 k 0.2493 -> 0.2478,
     // 1 k / 4 k unchanged within noise)
-    static const int target_env = getenv("PFSLAM_TARGET_WAVES") ? atoi(getenv("PFSLAM_TARGET_WAVES")) : 0;
+    static const int target_env = ab_env("PFSLAM_TARGET_WAVES") ? atoi(ab_env("PFSLAM_TARGET_WAVES")) : 0;
     const int target = target_env > 0 ? target_env : std::max(24576, std::min(65536, groups * 160));
     int chunks = (target + groups - 1) / groups;
     chunks = std::max(1, std::min(chunks, h->nb)); // small particle counts go down to one beam per wave
@@ -1594,7 +1613,7 @@ static int launch_cells_update(pfslam_handle *h, hipStream_t st)
     // move to the pool's end, and after ~20 frames the rows a wave gathers together no longer sit together -- the scan-match kernel,
     // with nothing running beside it, went from 0.37 to 0.40-0.42 ms between the 10th and the 20th frame after a wipe (the round-3
     // build, which cut everything every frame, stayed flat).  A cut needs no walk: the records hold the candidates.
-    static const int recut_every = getenv("PFSLAM_CELLS_RECUT_EVERY") ? atoi(getenv("PFSLAM_CELLS_RECUT_EVERY")) : 16; // (as in the round-5 frame: tools/experiments/r05/recut_ab.sh)
+    static const int recut_every = ab_env("PFSLAM_CELLS_RECUT_EVERY") ? atoi(ab_env("PFSLAM_CELLS_RECUT_EVERY")) : 16; // (as in the round-5 frame: tools/experiments/r05/recut_ab.sh)
     const int recut = recut_every > 0 && h->cells_passes > 0 && h->cells_passes % recut_every == 0 ? 1 : 0;
     if (recut) HIPCHK(hipMemsetAsync(h->cell_state + PF_CS_POOL, 0, 4, st));
     hipLaunchKernelGGL(k_cells_update<true>, dim3(PF_CELLS_GRID), dim3(64), 0, st, kd_view(h), geo, h->cell_tab, (const int *)h->cell_list, h->cell_state,
@@ -1626,7 +1645,7 @@ static bool org_use_cells(const pfslam_handle *h, bool *use_plan, bool frame_loo
     const bool organised = h->planar && h->variant != 2 && h->variant != 1 && h->n > 64 && (h->n >= plan_min_n || h->variant >= 3);
     const float Dside = h->n <= 400000 ? 64.0f : 128.0f;
     const float box_cells = 2.0f * (6.4f * h->cloud_sigma / Dside) * cbrtf(64.0f * Dside * Dside * Dside / (float)h->n) / std::min(h->cfg.map_res_x, h->cfg.map_res_y);
-    static const float box_max = getenv("PFSLAM_CELLS_BOX_MAX") ? (float)atof(getenv("PFSLAM_CELLS_BOX_MAX")) : 24.0f;
+    static const float box_max = ab_env("PFSLAM_CELLS_BOX_MAX") ? (float)atof(ab_env("PFSLAM_CELLS_BOX_MAX")) : 24.0f;
     const bool narrow = h->variant == 3 || !(box_cells > box_max);
     const bool use_cells = organised && h->lattice_ok && h->variant != 4 && !h->cells_suspended && narrow; // lattice-cell rows (kd_cells.hip.inc)
     if (use_plan) *use_plan = !use_cells && h->planar && h->variant != 2 && (h->n >= plan_min_n || h->variant >= 3);
@@ -1695,14 +1714,14 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // kernel, on this stream (stage-level calls, the first pass after a wipe, per-phase timing).  Asynchronous pass (frame loops):
     // marking and the walk of the new cells run on the aux stream UNDER the scan-match kernel, whose lanes take the generic traversal
     // in a cell that has no rows yet; k_cells_update publishes them behind the frame's insert (launch_map_update_device).
-    static const int cells_mode = getenv("PFSLAM_CELLS_MODE") ? atoi(getenv("PFSLAM_CELLS_MODE")) : 0; // 1: always synchronous (A/B)
+    static const int cells_mode = ab_env("PFSLAM_CELLS_MODE") ? atoi(ab_env("PFSLAM_CELLS_MODE")) : 0; // 1: always synchronous (A/B)
     const bool cells_sync = use_cells && (!h->cells_async || h->cells_wipe_pending || census != nullptr || cells_mode == 1);
     if (use_cells && h->cells_wipe_pending) {
         CHK(join_map(h)); // the previous frame's k_cells_update is the table's last writer
         CHK(cells_wipe(h));
     }
     // default: counting sort over Hilbert cells of the cloud (3 launches), 2^18 cells up to 400 k particles, 2^21 above
-    static const float theta_weight = getenv("PFSLAM_THETA_WEIGHT") ? (float)atof(getenv("PFSLAM_THETA_WEIGHT")) : 1.0f;
+    static const float theta_weight = ab_env("PFSLAM_THETA_WEIGHT") ? (float)atof(ab_env("PFSLAM_THETA_WEIGHT")) : 1.0f;
     if (h->variant != 1 && h->n > 64) {
         const int bits = h->n <= 400000 ? 6 : PF_CELL_BITS_MAX, ncell = 1 << (3 * bits);
         int *hist = h->cells, *cursor = h->cells + ncell, *tile_tot = h->cells + 2 * ncell;
@@ -1717,12 +1736,12 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // per lane (exact in any order) instead of writing `used` partials per lane for the reduce kernel to read back (33 MB per frame)
     // MEASURED AND OFF BY DEFAULT (PFSLAM_ACC_OUT=1 turns it on): the reduce kernel gets 10 us shorter and 33 MB of writes go away, but
     // 8.4 M float atomics cost the scan-match kernel 30 us (0.626 -> 0.656 ms) -- plain stores retire for free next to VALU-bound work
-    static const bool acc_enabled = getenv("PFSLAM_ACC_OUT") && atoi(getenv("PFSLAM_ACC_OUT")) != 0;
+    static const bool acc_enabled = ab_env("PFSLAM_ACC_OUT") && atoi(ab_env("PFSLAM_ACC_OUT")) != 0;
     const bool acc_out = acc_enabled && use_cells && h->integral_w && used > 1 && fuse_minmax && !census;
     const int direct = used > 1 ? 0 : 1;
     // beam-chunk partials of the cell-row kernel as 16-bit integers: integer weights, and a chunk's sum cannot leave the range
     const bool wide_reduce = used >= 256 && fuse_minmax && !sharded && h->goff == 0 && !acc_out;
-    static const bool p16_ok = !(getenv("PFSLAM_P16") && atoi(getenv("PFSLAM_P16")) == 0);
+    static const bool p16_ok = !(ab_env("PFSLAM_P16") && atoi(ab_env("PFSLAM_P16")) == 0);
     const bool p16 = p16_ok && use_cells && h->integral_w && used > 1 && fuse_minmax && !acc_out && !wide_reduce && (float)bpc * h->w_absmax <= 32767.0f;
     h->plan_valid = use_plan;
     h->cells_valid = use_cells;
@@ -1791,7 +1810,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
     // (an event that has long fired), and what this stream goes on with -- weights, sums, resample, the next dispersion and lane
     // order -- is shorter than the map update and off the chain.  With the scan-match kernel on this stream, the chain crossed
     // streams twice per frame (fork behind the best pose, join in front of the next scan-match), 12-17 us each.
-    static const bool aux_ok = !(getenv("PFSLAM_SCORE_ON_AUX") && atoi(getenv("PFSLAM_SCORE_ON_AUX")) == 0);
+    static const bool aux_ok = !(ab_env("PFSLAM_SCORE_ON_AUX") && atoi(ab_env("PFSLAM_SCORE_ON_AUX")) == 0);
     const bool on_aux = aux_ok && h->score_on_aux && use_cells && !cells_sync && fuse_minmax && !census && !sharded;
     h->scored_on_aux = on_aux;
     struct StreamSwap { // the rest of this function launches on h->stream: point it at the aux stream for that long
@@ -1882,7 +1901,7 @@ static int launch_score(pfslam_handle *h, bool fuse_minmax = false, pf::KdCensus
         HIPCHK(hipGetLastError());
     } else if (used > 1 && fuse_minmax) {
 #define PF_REDUCE4_WGS 128 /* workgroups of k_reduce_partials_minmax (grid-stride over the slots; see the kernel) */
-        static const int reduce4_wgs = getenv("PFSLAM_REDUCE4_WGS") ? std::max(1, atoi(getenv("PFSLAM_REDUCE4_WGS"))) : PF_REDUCE4_WGS; // (A/B: 1000000 = one workgroup per 256 slots)
+        static const int reduce4_wgs = ab_env("PFSLAM_REDUCE4_WGS") ? std::max(1, atoi(ab_env("PFSLAM_REDUCE4_WGS"))) : PF_REDUCE4_WGS; // (A/B: 1000000 = one workgroup per 256 slots)
         hipLaunchKernelGGL(k_reduce_partials_minmax, dim3(std::min((h->n + 255) / 256, reduce4_wgs)), dim3(256), 0, h->stream, acc_out ? h->fit_acc : h->partial, h->n,
                            acc_out ? 1 : used, order, h->fit, h->goff, (long long *)h->stats, h->x, h->y, h->th, acc_out ? 1 : 0, p16 ? 1 : 0);
         HIPCHK(hipGetLastError());

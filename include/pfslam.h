@@ -105,6 +105,9 @@ int pfslam_synchronize(pfslam_handle *h);
  * reference's synchronous particleFilter.  A deferred error (kd_capacity exhausted, cell list overflow) is returned by the call
  * that books the frame: the next pfslam_step, a getter, or pfslam_synchronize.  The first scan (it seeds the map on the host),
  * re-balance frames and handles with pfslam_set_topology(h, 1) are booked at once.
+ * One deferred error is fatal for the handle: "a stream gate ... gave up waiting" (a cross-stream edge of the frame was not served
+ * within 1 s: streams sharing a hardware queue, a multi-GPU peer that never arrived).  The launches behind that gate have run without
+ * what they waited for, so map, weights and particles are undefined from that frame on; the error is sticky -- destroy the handle.
  * pfslam_set_lag: 0 = every pfslam_step books its own frame before it returns, up to 2 frames in flight. */
 int pfslam_step(pfslam_handle *h, int frame, const float *scan_host);
 int pfslam_set_lag(pfslam_handle *h, int frames);

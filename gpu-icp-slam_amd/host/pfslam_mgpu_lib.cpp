@@ -39,6 +39,7 @@ struct pfslam_mgpu {
     // ACROSS streams (events) if the keys' all-gather on the chain stream shared one with the particle stream's two
     ncclComm_t comm_p = nullptr, comm_c = nullptr;
     int world = 1, rank = 0, stride = 0;
+    int device = 0; // the handle's GPU: ncclCommInitRank binds a communicator to the CURRENT device, so it is made current first
     int collectives = 0, balance_builds = 0, balance_broadcasts = 0;
     double *scratch = nullptr;
 };
@@ -117,6 +118,12 @@ extern "C" int pfslam_mgpu_create(const unsigned char *id, int world, int rank, 
             return mfail(std::string("pfslam_device_ptr: ") + pfslam_last_error());
         }
         m->stride = (int)(bytes / 4);
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess || hipSetDevice(attr.device) != hipSuccess) {
+            delete m;
+            return mfail("pfslam_mgpu_create: cannot make the handle's device current");
+        }
+        m->device = attr.device;
     }
     if (world > 1) {
         ncclUniqueId a, b;
@@ -165,6 +172,7 @@ extern "C" int pfslam_mgpu_destroy(pfslam_mgpu *m)
 extern "C" int pfslam_mgpu_step(pfslam_mgpu *m, int frame, const float *scan)
 {
     if (!m || !scan) return mfail("pfslam_mgpu_step: bad argument");
+    HIP(hipSetDevice(m->device));
     pfslam_handle *h = m->h;
     const bool comm = m->world > 1; // world 1: buffers 10 / 17 alias 5 / 16, nothing reads buffer 15, nothing to move
     if (comm) { // KDTree::Balance (frame % 100 == 5) ONCE per node: rank 0 builds, the others take its device arrays (28 B per node)
@@ -216,6 +224,7 @@ extern "C" int pfslam_mgpu_step(pfslam_mgpu *m, int frame, const float *scan)
 extern "C" int pfslam_mgpu_barrier_max(pfslam_mgpu *m, double *value)
 {
     if (!m) return mfail("pfslam_mgpu_barrier_max: null argument");
+    HIP(hipSetDevice(m->device));
     PF(pfslam_synchronize(m->h)); // books the frames in flight, joins the frame's streams into the handle's, waits for it
     HIP(hipDeviceSynchronize());
     if (m->world == 1) return 0;
@@ -245,6 +254,7 @@ extern "C" int pfslam_mgpu_time_collectives(pfslam_mgpu *m, int reps, float ms[3
     if (!m || !ms || reps <= 0) return mfail("pfslam_mgpu_time_collectives: bad argument");
     ms[0] = ms[1] = ms[2] = 0.0f;
     if (m->world == 1) return 0;
+    HIP(hipSetDevice(m->device));
     PF(pfslam_synchronize(m->h));
     HIP(hipDeviceSynchronize());
     hipEvent_t a, b;

@@ -297,6 +297,9 @@ def self_launch(n):
 
 
 def main():
+    # (multi-process GPU work on this host driver needs dmabuf IPC -- RCCL's hipIpcGetMemHandle fails otherwise; read by the HSA runtime
+    # when it initialises, i.e. before the package's library makes its first HIP call)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("PFSLAM_BENCH_WATCHDOG"):  # debugging aid: every thread's traceback after N seconds, then exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PFSLAM_BENCH_WATCHDOG"]), exit=True)

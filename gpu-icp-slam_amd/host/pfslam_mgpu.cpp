@@ -296,6 +296,9 @@ static int run_rank(const Args &a, int rank, int world, int local_rank, const st
 
 int main(int argc, char **argv)
 {
+    // multi-process GPU work on this host driver needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the HSA runtime reads the
+    // variable when it initialises -- before this process's, and its children's, first HIP call
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     Args a;
     if (!parse(argc, argv, a)) {
         printf("Usage: %s --gpus N MAP.nodes SCANS.f32 PARTICLES_PER_GPU [--steps K] [--warmup W] [--first-frame F] [--dump PREFIX] "

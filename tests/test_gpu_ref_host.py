@@ -180,5 +180,6 @@ def test_reference_frame_loop_against_the_product(pkg, tmp_path):
     # H4 as the reference really behaves: several cells of a pass that hit ONE node lose all but one of their updates when their threads
     # run together -- the product (and the restatement) apply every hit: the differences are whole multiples of the two weights, on a
     # few dozen of some thousand nodes per frame
-    assert all(v % 1 == 0 and (v % 4 == 0 or -8 <= v < 0) for v in stats["weights_lost_product_minus_reference"])
+    # (product - reference = 4 x lost wall hits - lost free hits of that node in that frame: a small integer either way)
+    assert all(v % 1 == 0 and -8 <= v <= 32 for v in stats["weights_lost_product_minus_reference"])
     assert stats["weights_lost"] < 0.05 * stats["frames"] * 1000

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 L=tools/experiments/r05/libs
 python tools/experiments/r06/gather_cost.py make /tmp/state30.npz 2>/dev/null
 for rep in 1 2; do
-  for v in base noslot0 oneline scatter; do
+  for v in base fp32ep; do
     PFSLAM_LIB=$PWD/$L/libpfslam_$v.so python tools/experiments/r06/gather_cost.py time /tmp/state30.npz 2>/dev/null
   done
 done

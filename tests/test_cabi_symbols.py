@@ -66,3 +66,23 @@ def test_whole_node_thread_budget():
     a, b, c = map(int, subprocess.check_output([sys.executable, "-c", code], env=env).split()[-3:])
     one = int(subprocess.check_output([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="1")).split()[-3])
     assert a == c == max(1, min(one, 64) // 8 if one >= 8 else 1) and b == one
+
+
+def test_environment_switches_are_the_documented_set():
+    """Housekeeping of round 6: the product build reads only the test / diagnostic switches tools/README.md lists; the A/B knobs of past
+    experiments go through ab_env(), which is getenv only under -DPF_EXPERIMENTS (not among the build's flags)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    allowed = {"PFSLAM_SERIAL", "PFSLAM_GATES", "PFSLAM_FAULT", "PFSLAM_STABLE_ORDER", "PFSLAM_MARK_EARLY", "PFSLAM_PUBLISH_LAG", "PFSLAM_VARIANT",
+               "PFSLAM_PLAN_MIN_N", "PFSLAM_CELL_LIST_CAP", "PFSLAM_CELL_POOL_CAP", "PFSLAM_SORT_THREADS", "PFSLAM_PLAIN_SORT", "PFSLAM_VERBOSE"}
+    read = set()
+    for f in glob.glob(os.path.join(root, "gpu-icp-slam_amd", "csrc", "*")):
+        if f.endswith((".hip", ".inc", ".h", ".cpp")):
+            src = open(f).read()
+            read |= set(re.findall(r'[^_a-z]getenv\("(PFSLAM_[A-Z0-9_]+)"\)', src))
+    assert read <= allowed, "undocumented environment switch in the product build: %s" % sorted(read - allowed)
+    readme = open(os.path.join(root, "tools", "README.md")).read()
+    assert all(name in readme for name in read)
+    build = open(os.path.join(root, "gpu-icp-slam_amd", "build.py")).read()
+    assert "PF_EXPERIMENTS" not in build.split("FLAGS =")[1].split("\n")[0]
